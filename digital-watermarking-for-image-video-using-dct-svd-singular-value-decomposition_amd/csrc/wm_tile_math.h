@@ -1,0 +1,323 @@
+// Per-tile arithmetic of the DCT-SVD watermark hot path: one 8x8 tile per
+// GPU lane, everything in registers (no LDS, no cross-lane traffic).
+//
+// Reference statements this replaces (citations into /root/reference,
+// app_dct_svd_single.py = "single"), applied to one 8x8 tile instead of the
+// whole plane (tile-mode):
+//   a2  dct2            single:32-33   -> dct8x8()
+//   a3  np.linalg.svd   single:172-173 -> jacobi_svd8()   (one-sided Jacobi)
+//   a4  S_[:K] += a*Sw  single:174-175 -> embed_tile()
+//   a5  U diag(S_) Vt   single:176     -> embed_tile()
+//   a6  idct2           single:35-36   -> idct8x8()
+//   a7  clip + astype   single:27      -> quant_u8()       (truncation)
+//   a8  (S_cw-Sc)/alpha single:212-213 -> extract_tile()
+//   a9  Uw diag() Vwt   single:214-218 -> extract_tile()
+//
+// The header is host/device: hipcc compiles it into the gfx950 kernels
+// (wm_kernels.hip); tests compile the very same functions with g++ to check
+// the arithmetic on the CPU (tests/host_harness.cpp).  The host build is a
+// test harness, never a product path.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define WM_HD __host__ __device__ __forceinline__
+#else
+#define WM_HD inline
+#endif
+
+namespace wm {
+
+// ---- fast reciprocal / sqrt (v_rcp_f32, v_rsq_f32, v_sqrt_f32: 1 ulp) -------
+WM_HD float frcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+WM_HD float frsq(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+WM_HD float fsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+WM_HD float ffma(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_fmaf(a, b, c);
+#else
+  return fmaf(a, b, c);
+#endif
+}
+// wave-wide OR of a per-lane predicate (host: identity)
+WM_HD bool wave_any(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(p) != 0ull;
+#else
+  return p;
+#endif
+}
+
+// ---- 8-point orthonormal DCT-II constants: D[k][m] = ck*cos((2m+1)k*pi/16) --
+// c_k = 0.5*cos(k*pi/16) for k>=1; row 0 is sqrt(1/8) = C4.
+constexpr float C1 = 0.49039264020161522f;
+constexpr float C2 = 0.46193976625564337f;
+constexpr float C3 = 0.41573480615127262f;
+constexpr float C4 = 0.35355339059327379f;
+constexpr float C5 = 0.27778511650980114f;
+constexpr float C6 = 0.19134171618254492f;
+constexpr float C7 = 0.09754516100806417f;
+
+// forward 1-D DCT-II of 8 samples, even/odd split (36 flop-instr)
+WM_HD void dct8(float& x0, float& x1, float& x2, float& x3,
+                float& x4, float& x5, float& x6, float& x7) {
+  const float s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
+  const float d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
+  const float e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+  x0 = C4 * (e0 + e1);
+  x4 = C4 * (e0 - e1);
+  x2 = ffma(C2, e2, C6 * e3);
+  x6 = ffma(C6, e2, -C2 * e3);
+  x1 = ffma(C1, d0, ffma(C3, d1, ffma(C5, d2, C7 * d3)));
+  x3 = ffma(C3, d0, ffma(-C7, d1, ffma(-C1, d2, -C5 * d3)));
+  x5 = ffma(C5, d0, ffma(-C1, d1, ffma(C7, d2, C3 * d3)));
+  x7 = ffma(C7, d0, ffma(-C5, d1, ffma(C3, d2, -C1 * d3)));
+}
+
+// inverse (DCT-III with the same orthonormal scaling)
+WM_HD void idct8(float& x0, float& x1, float& x2, float& x3,
+                 float& x4, float& x5, float& x6, float& x7) {
+  const float p = C4 * (x0 + x4), q = C4 * (x0 - x4);
+  const float r = ffma(C2, x2, C6 * x6), t = ffma(C6, x2, -C2 * x6);
+  const float e0 = p + r, e3 = p - r, e1 = q + t, e2 = q - t;
+  const float o0 = ffma(C1, x1, ffma(C3, x3, ffma(C5, x5, C7 * x7)));
+  const float o1 = ffma(C3, x1, ffma(-C7, x3, ffma(-C1, x5, -C5 * x7)));
+  const float o2 = ffma(C5, x1, ffma(-C1, x3, ffma(C7, x5, C3 * x7)));
+  const float o3 = ffma(C7, x1, ffma(-C5, x3, ffma(C3, x5, -C1 * x7)));
+  x0 = e0 + o0; x7 = e0 - o0;
+  x1 = e1 + o1; x6 = e1 - o1;
+  x2 = e2 + o2; x5 = e2 - o2;
+  x3 = e3 + o3; x4 = e3 - o3;
+}
+
+// 2-D transforms on a[row][col]:  C = D X D^T   /   X = D^T C D
+WM_HD void dct8x8(float (&a)[8][8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    dct8(a[0][c], a[1][c], a[2][c], a[3][c], a[4][c], a[5][c], a[6][c], a[7][c]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    dct8(a[r][0], a[r][1], a[r][2], a[r][3], a[r][4], a[r][5], a[r][6], a[r][7]);
+}
+WM_HD void idct8x8(float (&a)[8][8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    idct8(a[r][0], a[r][1], a[r][2], a[r][3], a[r][4], a[r][5], a[r][6], a[r][7]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    idct8(a[0][c], a[1][c], a[2][c], a[3][c], a[4][c], a[5][c], a[6][c], a[7][c]);
+}
+
+// ---- one-sided (Hestenes) Jacobi SVD of an 8x8 matrix ------------------------
+// Row-cyclic pair order with de Rijk's norm ordering (the larger column of a
+// pair always ends in the lower index), so singular values come out sorted
+// descending like LAPACK's.  On return
+//   a  = B = A*V     (mutually orthogonal columns, |b_i| descending)
+//   v  = V           (accumulated plane rotations; WITH_V only)
+//   n2 = |b_i|^2 ,  vn2 = |v_i|^2 (exactly 1 in exact arithmetic; carried so the
+//        1-ulp drift of v_rsq_f32 cancels in sigma_i = |b_i| / |v_i|).
+// Sweeps stop when a whole sweep saw no pair with cos^2 > CONV2 for any tile
+// of the wave (Jacobi converges quadratically: a sweep that starts below
+// 3e-4 ends at rounding level), bounded by MAX_SWEEPS.
+constexpr float JAC_TOL2 = 1e-15f;   // skip a rotation below cos = 3.2e-8
+constexpr float JAC_CONV2 = 1e-7f;   // "converged" sweep: max cos < 3.2e-4
+constexpr int JAC_MAX_SWEEPS = 12;
+
+template <bool WITH_V>
+WM_HD void jacobi_rot(float (&a)[8][8], float (&v)[8][8], float (&n2)[8],
+                      const int p, const int q, bool& notconv) {
+  float g = a[0][p] * a[0][q];
+#pragma unroll
+  for (int r = 1; r < 8; ++r) g = ffma(a[r][p], a[r][q], g);
+  const float al = n2[p], be = n2[q];
+  const float ab = al * be, gg = g * g;
+  const bool big = gg > JAC_TOL2 * ab;
+  notconv = notconv || (gg > JAC_CONV2 * ab);
+  const float tau = be - al, g2 = g + g;
+  const float h = fsqrt(ffma(tau, tau, g2 * g2));
+  float t = g2 * frcp(fabsf(tau) + h);     // 0/0 only when g == 0 -> !big
+  t = (tau < 0.0f) ? -t : t;
+  t = big ? t : 0.0f;
+  const float c = frsq(ffma(t, t, 1.0f)), s = c * t;
+  const float tg = t * g;
+  const float aln = al - tg, ben = be + tg;
+  const bool sw = tau > 0.0f;              // |a_q| > |a_p|: rotate a further 90 deg
+  const float C = sw ? s : c, S = sw ? -c : s;
+  n2[p] = sw ? ben : aln;
+  n2[q] = sw ? aln : ben;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float x = a[r][p], y = a[r][q];
+    a[r][p] = ffma(C, x, -S * y);
+    a[r][q] = ffma(S, x, C * y);
+  }
+  if (WITH_V) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float x = v[r][p], y = v[r][q];
+      v[r][p] = ffma(C, x, -S * y);
+      v[r][q] = ffma(S, x, C * y);
+    }
+  }
+}
+
+WM_HD void col_norms2(const float (&a)[8][8], float (&n2)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float s = a[0][c] * a[0][c];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) s = ffma(a[r][c], a[r][c], s);
+    n2[c] = s;
+  }
+}
+
+template <bool WITH_V>
+WM_HD int jacobi_svd8(float (&a)[8][8], float (&v)[8][8], float (&n2)[8], float (&vn2)[8]) {
+  if (WITH_V) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[r][c] = (r == c) ? 1.0f : 0.0f;
+  }
+  int sweep = 0;
+  bool more = true;
+  while (more && sweep < JAC_MAX_SWEEPS) {
+    col_norms2(a, n2);
+    bool notconv = false;
+#pragma unroll
+    for (int p = 0; p < 7; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 8; ++q) jacobi_rot<WITH_V>(a, v, n2, p, q, notconv);
+    ++sweep;
+    more = wave_any(notconv);
+  }
+  col_norms2(a, n2);
+  if (WITH_V) col_norms2(v, vn2);
+  else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) vn2[c] = 1.0f;
+  }
+  return more ? -sweep : sweep;   // negative: sweep bound hit before convergence
+}
+
+// ---- uint8 quantisation: np.clip(x, 0, 255).astype(np.uint8) ----------------
+WM_HD uint32_t quant_u8(float x) {
+  x = fminf(fmaxf(x, 0.0f), 255.0f);   // NaN -> 0 via fmaxf
+  return (uint32_t)x;                  // truncation toward zero
+}
+
+// ---- embed: tile (already float, pixel domain) -> stego tile (float) --------
+// sw[8]: the watermark tile's singular values; alpha_k[i] = alpha for i < K,
+// 0 otherwise.  sc[8] receives the host tile's singular values.
+WM_HD int embed_tile(float (&a)[8][8], const float (&sw)[8], const float (&alpha_k)[8],
+                     float (&sc)[8]) {
+  float v[8][8], n2[8], vn2[8];
+  dct8x8(a);
+  const int sweeps = jacobi_svd8<true>(a, v, n2, vn2);
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float nb = fsqrt(n2[i]), nv = fsqrt(vn2[i]);
+    const float sig = nb * frcp(nv);                      // sigma_i = |b_i| / |v_i|
+    sc[i] = sig;
+    const float sp = ffma(alpha_k[i], sw[i], sig);        // S_[:K] = Sc[:K] + alpha*Sw[:K]
+    const float den = nb * nv;
+    f[i] = (den > 0.0f) ? sp * frcp(den) : 0.0f;          // sigma'_i / (|b_i| |v_i|)
+  }
+  // Cw = sum_i (b_i f_i) v_i^T   ==  U diag(S_) V^T
+  float cw[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float bs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bs[i] = a[r][i] * f[i];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float s = bs[0] * v[c][0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) s = ffma(bs[i], v[c][i], s);
+      cw[r][c] = s;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[r][c] = cw[r][c];
+  idct8x8(a);
+  return sweeps;
+}
+
+// ---- sigma only (extract / detect): tile -> singular values -----------------
+WM_HD int sigma_tile(float (&a)[8][8], float (&s)[8]) {
+  float n2[8], vn2[8];
+  dct8x8(a);
+  const int sweeps = jacobi_svd8<false>(a, a /*unused*/, n2, vn2);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = fsqrt(n2[i]);
+  return sweeps;
+}
+
+// ---- full SVD of a float tile (watermark side): U, S, Vt --------------------
+// u[r][i], vt[i][c]; columns with sigma == 0 get u_i = 0.
+WM_HD int svd_tile(float (&a)[8][8], float (&s)[8], float (&vt)[8][8]) {
+  float v[8][8], n2[8], vn2[8];
+  dct8x8(a);
+  const int sweeps = jacobi_svd8<true>(a, v, n2, vn2);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float rb = (n2[i] > 0.0f) ? frsq(n2[i]) : 0.0f;
+    const float rv = frsq(vn2[i]);
+    s[i] = fsqrt(n2[i]) * rv;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r][i] *= rb;            // U = B / |b_i|
+#pragma unroll
+    for (int c = 0; c < 8; ++c) vt[i][c] = v[c][i] * rv;  // Vt = (V / |v_i|)^T
+  }
+  return sweeps;
+}
+
+// ---- extract: Wm_hat = Uw diag(sw_hat) Vwt, then IDCT (a8 + a9) -------------
+// s_cw/sc: stego and stored host singular values; inv_alpha = 1/max(alpha,1e-8);
+// keep[i] = 1 for i < K else 0.  out <- idct(Uw diag(sw_hat) Vwt).
+WM_HD void extract_tile(const float (&s_cw)[8], const float (&sc)[8], const float inv_alpha,
+                        const float (&keep)[8], const float (&uw)[8][8],
+                        const float (&vwt)[8][8], float (&out)[8][8]) {
+  float sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sh[i] = (s_cw[i] - sc[i]) * inv_alpha * keep[i];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float us[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) us[i] = uw[r][i] * sh[i];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float s = us[0] * vwt[0][c];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) s = ffma(us[i], vwt[i][c], s);
+      out[r][c] = s;
+    }
+  }
+  idct8x8(out);
+}
+
+}  // namespace wm

@@ -1,0 +1,903 @@
+// libwmhip.so - gfx950 kernels + C ABI (include/wmhip.h) of the tile-mode
+// DCT-SVD watermark hot path.
+//
+// Execution model: ONE 8x8 TILE PER LANE.  A wave64 owns 64 consecutive tiles
+// (row-major tile order); every load/store instruction of a wave touches
+// 64 x 8 B = 512 contiguous bytes of one image row (coalesced), and the whole
+// DCT -> one-sided Jacobi SVD -> perturb -> reconstruct -> IDCT -> quantise
+// chain runs out of VGPRs with compile-time register indices: no LDS round
+// trips, no cross-lane shuffles, no divergence (the sweep loop is
+// wave-uniform).  The path is VALU-bound (~10^4 FMA-class instructions per
+// tile against 3 B per pixel); see DESIGN.md for the roofline.
+//
+//   hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o libwmhip.so wmhip.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/wmhip.h"
+#include "wm_tile_math.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int N_EVENTS = 16;
+constexpr int N_SUMS = 5;          // detect: sum a, b, ab, aa, bb
+
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char* fmt, const char* a = "", const char* b = "") {
+  snprintf(g_err, sizeof(g_err), fmt, a, b);
+  return code;
+}
+
+#define WM_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return set_err(WM_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define WM_TRY(call)            \
+  do {                          \
+    int rc_ = (call);           \
+    if (rc_ != WM_OK) return rc_; \
+  } while (0)
+
+}  // namespace
+
+struct wm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  int* d_status = nullptr;        // sticky kernel status word
+  void* scratch = nullptr;        // grow-only device scratch (host-pointer wrappers)
+  size_t scratch_bytes = 0;
+  void* partials = nullptr;       // grow-only detect partial sums
+  size_t partials_bytes = 0;
+  hipEvent_t ev[N_EVENTS] = {};
+};
+
+namespace {
+
+int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what) {
+  if (bytes <= *have) return WM_OK;
+  if (*buf) {
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    WM_HIP(hipFree(*buf));
+    *buf = nullptr; *have = 0;
+  }
+  const size_t mb = (size_t)1 << 20;
+  const size_t want = (bytes + mb - 1) / mb * mb;
+  if (hipMalloc(buf, want) != hipSuccess) {
+    (void)hipGetLastError();
+    *buf = nullptr;
+    return set_err(WM_ERR_NOMEM, "hipMalloc failed for %s", what);
+  }
+  *have = want;
+  return WM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tile I/O (per lane)
+// ---------------------------------------------------------------------------
+template <bool ALIGNED>
+__device__ __forceinline__ void load_tile_u8(const uint8_t* __restrict__ p, const size_t stride,
+                                             float (&a)[8][8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    uint32_t lo, hi;
+    if (ALIGNED) {
+      const uint2 w = *reinterpret_cast<const uint2*>(p + r * stride);
+      lo = w.x; hi = w.y;
+    } else {
+      const uint8_t* q = p + r * stride;
+      lo = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+      hi = q[4] | (q[5] << 8) | (q[6] << 16) | ((uint32_t)q[7] << 24);
+    }
+    a[r][0] = (float)(lo & 0xffu); a[r][1] = (float)((lo >> 8) & 0xffu);
+    a[r][2] = (float)((lo >> 16) & 0xffu); a[r][3] = (float)(lo >> 24);
+    a[r][4] = (float)(hi & 0xffu); a[r][5] = (float)((hi >> 8) & 0xffu);
+    a[r][6] = (float)((hi >> 16) & 0xffu); a[r][7] = (float)(hi >> 24);
+  }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void store_tile_u8(uint8_t* __restrict__ p, const size_t stride,
+                                              const float (&a)[8][8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t lo = wm::quant_u8(a[r][0]) | (wm::quant_u8(a[r][1]) << 8) |
+                        (wm::quant_u8(a[r][2]) << 16) | (wm::quant_u8(a[r][3]) << 24);
+    const uint32_t hi = wm::quant_u8(a[r][4]) | (wm::quant_u8(a[r][5]) << 8) |
+                        (wm::quant_u8(a[r][6]) << 16) | (wm::quant_u8(a[r][7]) << 24);
+    if (ALIGNED) {
+      *reinterpret_cast<uint2*>(p + r * stride) = make_uint2(lo, hi);
+    } else {
+      uint8_t* q = p + r * stride;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        q[i] = (uint8_t)(lo >> (8 * i));
+        q[4 + i] = (uint8_t)(hi >> (8 * i));
+      }
+    }
+  }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void load_row8_f32(const float* __restrict__ p, float (&row)[8]) {
+  if (VEC) {
+    const float4 x = *reinterpret_cast<const float4*>(p);
+    const float4 y = *reinterpret_cast<const float4*>(p + 4);
+    row[0] = x.x; row[1] = x.y; row[2] = x.z; row[3] = x.w;
+    row[4] = y.x; row[5] = y.y; row[6] = y.z; row[7] = y.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) row[i] = p[i];
+  }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void store_row8_f32(float* __restrict__ p, const float (&row)[8]) {
+  if (VEC) {
+    *reinterpret_cast<float4*>(p) = make_float4(row[0], row[1], row[2], row[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(row[4], row[5], row[6], row[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = row[i];
+  }
+}
+
+// 8x8 float matrix stored contiguously (tile-major meta arrays: 256 B per tile)
+__device__ __forceinline__ void load_mat_f32(const float* __restrict__ p, float (&m)[8][8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) load_row8_f32<true>(p + r * 8, m[r]);
+}
+__device__ __forceinline__ void store_mat_f32(float* __restrict__ p, const float (&m)[8][8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) store_row8_f32<true>(p + r * 8, m[r]);
+}
+
+struct Geom {
+  int nbx;          // tiles per tile-row
+  int n_tiles;      // tiles per plane
+  int W;            // plane width (dense float outputs use W as row stride)
+  size_t HW;        // H * W
+  size_t row_stride;
+  size_t plane_stride;
+};
+
+__device__ __forceinline__ bool tile_coords(const Geom& g, int& t, int& ty, int& tx) {
+  t = blockIdx.x * WAVE + threadIdx.x;
+  if (t >= g.n_tiles) return false;
+  ty = t / g.nbx;
+  tx = t - ty * g.nbx;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// K1  fused embed   (a1 a2 a3 a4 a5 a6 a7; sigma_c side output)
+// ---------------------------------------------------------------------------
+template <bool ALIGNED, bool VECF>
+__global__ __launch_bounds__(WAVE) void k_embed_tiles(
+    const uint8_t* host, const float* __restrict__ sigma_w,
+    uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
+    const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
+    int* __restrict__ status) {
+  int t, ty, tx;
+  if (!tile_coords(g, t, ty, tx)) return;
+  const size_t plane = blockIdx.y;
+  const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
+
+  float a[8][8], sw[8], sc[8], alpha_k[8];
+  load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
+  load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
+
+  const int sweeps = wm::embed_tile(a, sw, alpha_k, sc);
+  if (sweeps < 0) atomicOr(status, 1);
+
+  store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
+  store_tile_u8<ALIGNED>(stego + off, g.row_stride, a);
+  if (yw != nullptr) {
+    float* o = yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
+  }
+}
+
+// copy the rows/columns no tile covers (H % 8, W % 8) from host to stego,
+// and into yw as float
+__global__ void k_copy_border(const uint8_t* host, uint8_t* stego,
+                              float* __restrict__ yw, const int H, const int W, const int Hb,
+                              const int Wb, const size_t row_stride, const size_t plane_stride) {
+  const size_t plane = blockIdx.y;
+  const int n_right = (W - Wb) * Hb;            // right strip: rows [0,Hb) cols [Wb,W)
+  const int n_bottom = (H - Hb) * W;            // bottom strip: rows [Hb,H) all cols
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_right + n_bottom;
+       i += gridDim.x * blockDim.x) {
+    int r, c;
+    if (i < n_right) { r = i / (W - Wb); c = Wb + i % (W - Wb); }
+    else { const int j = i - n_right; r = Hb + j / W; c = j % W; }
+    const size_t o = plane * plane_stride + (size_t)r * row_stride + c;
+    const uint8_t px = host[o];
+    if (stego != host) stego[o] = px;
+    if (yw) yw[plane * (size_t)H * W + (size_t)r * W + c] = (float)px;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2  sigma only
+// ---------------------------------------------------------------------------
+template <bool ALIGNED>
+__global__ __launch_bounds__(WAVE) void k_sigma_tiles(const uint8_t* __restrict__ planes,
+                                                     float* __restrict__ sigma, const Geom g,
+                                                     int* __restrict__ status) {
+  int t, ty, tx;
+  if (!tile_coords(g, t, ty, tx)) return;
+  const size_t plane = blockIdx.y;
+  float a[8][8], s[8];
+  load_tile_u8<ALIGNED>(planes + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
+                        g.row_stride, a);
+  if (wm::sigma_tile(a, s) < 0) atomicOr(status, 1);
+  store_row8_f32<true>(sigma + (plane * g.n_tiles + t) * 8, s);
+}
+
+// ---------------------------------------------------------------------------
+// K3  full SVD of float tiles (watermark side)
+// ---------------------------------------------------------------------------
+template <bool VECF>
+__global__ __launch_bounds__(WAVE) void k_svd_tiles(const float* __restrict__ planes,
+                                                   float* __restrict__ U, float* __restrict__ S,
+                                                   float* __restrict__ Vt, const Geom g,
+                                                   int* __restrict__ status) {
+  int t, ty, tx;
+  if (!tile_coords(g, t, ty, tx)) return;
+  const size_t plane = blockIdx.y;
+  const float* p = planes + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
+  float a[8][8], s[8], vt[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) load_row8_f32<VECF>(p + (size_t)r * g.row_stride, a[r]);
+  if (wm::svd_tile(a, s, vt) < 0) atomicOr(status, 1);
+  const size_t ti = plane * g.n_tiles + t;
+  store_row8_f32<true>(S + ti * 8, s);
+  store_mat_f32(U + ti * 64, a);
+  store_mat_f32(Vt + ti * 64, vt);
+}
+
+// ---------------------------------------------------------------------------
+// K2+K4  fused extract
+// ---------------------------------------------------------------------------
+template <bool ALIGNED, bool VECF>
+__global__ __launch_bounds__(WAVE) void k_extract_tiles(
+    const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
+    const float* __restrict__ Uw, const float* __restrict__ Vwt, float* __restrict__ out,
+    const Geom g, const size_t uv_plane_stride, const float inv_alpha, const int K,
+    int* __restrict__ status) {
+  int t, ty, tx;
+  if (!tile_coords(g, t, ty, tx)) return;
+  const size_t plane = blockIdx.y;
+  float a[8][8], s[8], sc[8], keep[8];
+  load_tile_u8<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
+                        g.row_stride, a);
+  if (wm::sigma_tile(a, s) < 0) atomicOr(status, 1);
+  load_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) keep[i] = (i < K) ? 1.0f : 0.0f;
+  float uw[8][8], vwt[8][8];
+  const size_t mi = (plane * uv_plane_stride + (size_t)t) * 64;
+  load_mat_f32(Uw + mi, uw);
+  load_mat_f32(Vwt + mi, vwt);
+  wm::extract_tile(s, sc, inv_alpha, keep, uw, vwt, a);
+  float* o = out + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
+}
+
+// ---------------------------------------------------------------------------
+// K4  reconstruct only:  Uw diag(sw_hat) Vwt -> idct
+// ---------------------------------------------------------------------------
+template <bool VECF>
+__global__ __launch_bounds__(WAVE) void k_reconstruct_tiles(
+    const float* __restrict__ Uw, const float* __restrict__ sw_hat,
+    const float* __restrict__ Vwt, float* __restrict__ out, const Geom g) {
+  int t, ty, tx;
+  if (!tile_coords(g, t, ty, tx)) return;
+  const size_t plane = blockIdx.y;
+  const size_t ti = plane * g.n_tiles + t;
+  float sh[8], zero[8], one[8], uw[8][8], vwt[8][8], a[8][8];
+  load_row8_f32<true>(sw_hat + ti * 8, sh);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { zero[i] = 0.0f; one[i] = 1.0f; }
+  load_mat_f32(Uw + ti * 64, uw);
+  load_mat_f32(Vwt + ti * 64, vwt);
+  wm::extract_tile(sh, zero, 1.0f, one, uw, vwt, a);   // (sh - 0) * 1 * 1
+  float* o = out + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
+}
+
+// ---------------------------------------------------------------------------
+// K2+K5  fused detect: per-wave partial sums, then one block per plane
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, WAVE);
+  return x;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(WAVE) void k_detect_tiles(
+    const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
+    const float* __restrict__ sigma_w, double* __restrict__ partials, const Geom g,
+    const size_t sw_plane_stride, const float inv_alpha, int* __restrict__ status) {
+  const int t = blockIdx.x * WAVE + threadIdx.x;
+  const size_t plane = blockIdx.y;
+  double acc[N_SUMS] = {0, 0, 0, 0, 0};
+  if (t < g.n_tiles) {
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
+    float a[8][8], s[8], sc[8], sw[8];
+    load_tile_u8<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
+                          g.row_stride, a);
+    if (wm::sigma_tile(a, s) < 0) atomicOr(status, 1);
+    load_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
+    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double x = (double)sw[i];
+      const double y = (double)((s[i] - sc[i]) * inv_alpha);
+      acc[0] += x; acc[1] += y; acc[2] += x * y; acc[3] += x * x; acc[4] += y * y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N_SUMS; ++k) acc[k] = wave_sum(acc[k]);
+  if (threadIdx.x == 0) {
+    double* o = partials + (plane * gridDim.x + blockIdx.x) * N_SUMS;
+#pragma unroll
+    for (int k = 0; k < N_SUMS; ++k) o[k] = acc[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_detect_finalize(const double* __restrict__ partials,
+                                                        double* __restrict__ scores,
+                                                        const int n_waves, const double n_vals) {
+  __shared__ double sm[4][N_SUMS];
+  const size_t plane = blockIdx.x;
+  double acc[N_SUMS] = {0, 0, 0, 0, 0};
+  for (int w = threadIdx.x; w < n_waves; w += blockDim.x) {
+    const double* p = partials + (plane * n_waves + w) * N_SUMS;
+#pragma unroll
+    for (int k = 0; k < N_SUMS; ++k) acc[k] += p[k];
+  }
+#pragma unroll
+  for (int k = 0; k < N_SUMS; ++k) acc[k] = wave_sum(acc[k]);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N_SUMS; ++k) sm[threadIdx.x >> 6][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s[N_SUMS];
+#pragma unroll
+    for (int k = 0; k < N_SUMS; ++k) s[k] = sm[0][k] + sm[1][k] + sm[2][k] + sm[3][k];
+    double score = 0.0;
+    if (n_vals > 0) {
+      // _nc (single:284-289): mean-removed correlation, +1e-8 in the denominator
+      const double cov = s[2] - s[0] * s[1] / n_vals;
+      double va = s[3] - s[0] * s[0] / n_vals;
+      double vb = s[4] - s[1] * s[1] / n_vals;
+      va = va > 0 ? va : 0;
+      vb = vb > 0 ? vb : 0;
+      score = cov / (sqrt(va) * sqrt(vb) + 1e-8);
+    }
+    scores[plane] = score;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-side argument checking / launch helpers
+// ---------------------------------------------------------------------------
+int check_plane_args(const wm_ctx* ctx, const void* p, int n_planes, int H, int W, int row_stride,
+                     size_t plane_stride) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  if (n_planes < 0 || H < 0 || W < 0) return set_err(WM_ERR_BADARG, "negative size");
+  if (!p && n_planes > 0 && H > 0 && W > 0) return set_err(WM_ERR_BADARG, "plane pointer is NULL");
+  if (n_planes > 65535) return set_err(WM_ERR_BADARG, "n_planes > 65535");
+  if (row_stride < W) return set_err(WM_ERR_BADARG, "row_stride < W");
+  if (n_planes > 1 && plane_stride < (size_t)row_stride * (size_t)(H > 0 ? H - 1 : 0) + (size_t)W)
+    return set_err(WM_ERR_BADARG, "plane_stride smaller than one plane");
+  return WM_OK;
+}
+
+Geom make_geom(int H, int W, int row_stride, size_t plane_stride) {
+  Geom g;
+  g.nbx = W / 8;
+  g.n_tiles = (H / 8) * (W / 8);
+  g.W = W;
+  g.HW = (size_t)H * (size_t)W;
+  g.row_stride = (size_t)row_stride;
+  g.plane_stride = plane_stride;
+  return g;
+}
+
+inline bool u8_aligned(const void* a, const void* b, int row_stride, size_t plane_stride) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)row_stride | (uintptr_t)plane_stride) & 7u) == 0;
+}
+inline bool f32_vec_ok(const void* p, size_t row_stride_elems, size_t plane_stride_elems) {
+  return (((uintptr_t)p) & 15u) == 0 && (row_stride_elems & 3u) == 0 && (plane_stride_elems & 3u) == 0;
+}
+
+inline dim3 tile_grid(const Geom& g, int n_planes) {
+  return dim3((unsigned)((g.n_tiles + WAVE - 1) / WAVE), (unsigned)n_planes, 1);
+}
+
+}  // namespace
+
+namespace {
+struct Carve {
+  char* base; size_t off;
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+inline size_t plane_span(int n_planes, int H, int row_stride, size_t plane_stride, int W) {
+  if (n_planes == 0 || H == 0) return 0;
+  return (size_t)(n_planes - 1) * plane_stride + (size_t)(H - 1) * row_stride + (size_t)W;
+}
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int wm_abi_version(void) { return WM_ABI_VERSION; }
+const char* wm_last_error(void) { return g_err; }
+
+int wm_device_count(int* n_out) {
+  if (!n_out) return set_err(WM_ERR_BADARG, "n_out is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  *n_out = n;
+  return WM_OK;
+}
+
+int wm_create(int device, void* stream, wm_ctx** ctx_out) {
+  if (!ctx_out) return set_err(WM_ERR_BADARG, "ctx_out is NULL");
+  *ctx_out = nullptr;
+  int n = 0;
+  WM_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return set_err(WM_ERR_BADARG, "device index out of range");
+  WM_HIP(hipSetDevice(device));
+  wm_ctx* ctx = new (std::nothrow) wm_ctx();
+  if (!ctx) return set_err(WM_ERR_NOMEM, "host allocation failed");
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return set_err(WM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    ctx->owns_stream = true;
+  }
+  hipError_t e = hipMalloc((void**)&ctx->d_status, sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream);
+  for (int i = 0; i < N_EVENTS && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+  if (e != hipSuccess) { wm_destroy(ctx); return set_err(WM_ERR_HIP, "context setup: %s", hipGetErrorString(e)); }
+  *ctx_out = ctx;
+  return WM_OK;
+}
+
+int wm_destroy(wm_ctx* ctx) {
+  if (!ctx) return WM_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < N_EVENTS; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->partials) (void)hipFree(ctx->partials);
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return WM_OK;
+}
+
+int wm_sync(wm_ctx* ctx) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+int wm_check_status(wm_ctx* ctx) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  int st = 0;
+  WM_HIP(hipMemcpyAsync(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  if (st != 0) {
+    WM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+    return set_err(WM_ERR_NOCONV, "SVD did not converge");
+  }
+  return WM_OK;
+}
+
+int wm_malloc(wm_ctx* ctx, size_t bytes, void** dptr_out) {
+  if (!ctx || !dptr_out) return set_err(WM_ERR_BADARG, "NULL argument");
+  WM_HIP(hipSetDevice(ctx->device));
+  *dptr_out = nullptr;
+  if (hipMalloc(dptr_out, bytes ? bytes : 1) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(WM_ERR_NOMEM, "hipMalloc failed");
+  }
+  return WM_OK;
+}
+
+int wm_free(wm_ctx* ctx, void* dptr) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  if (dptr) { WM_HIP(hipStreamSynchronize(ctx->stream)); WM_HIP(hipFree(dptr)); }
+  return WM_OK;
+}
+
+int wm_memcpy_h2d(wm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!ctx || (bytes && (!dst_dev || !src_host))) return set_err(WM_ERR_BADARG, "NULL argument");
+  if (bytes) WM_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return WM_OK;
+}
+
+int wm_memcpy_d2h(wm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!ctx || (bytes && (!dst_host || !src_dev))) return set_err(WM_ERR_BADARG, "NULL argument");
+  if (bytes) {
+    WM_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return WM_OK;
+}
+
+int wm_memset(wm_ctx* ctx, void* dst_dev, int value, size_t bytes) {
+  if (!ctx || (bytes && !dst_dev)) return set_err(WM_ERR_BADARG, "NULL argument");
+  if (bytes) WM_HIP(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+  return WM_OK;
+}
+
+int wm_event_record(wm_ctx* ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= N_EVENTS) return set_err(WM_ERR_BADARG, "bad event slot");
+  WM_HIP(hipEventRecord(ctx->ev[slot], ctx->stream));
+  return WM_OK;
+}
+
+int wm_event_elapsed_ms(wm_ctx* ctx, int slot_start, int slot_stop, float* ms_out) {
+  if (!ctx || !ms_out || slot_start < 0 || slot_start >= N_EVENTS || slot_stop < 0 || slot_stop >= N_EVENTS)
+    return set_err(WM_ERR_BADARG, "bad event slot");
+  WM_HIP(hipEventSynchronize(ctx->ev[slot_stop]));
+  WM_HIP(hipEventElapsedTime(ms_out, ctx->ev[slot_start], ctx->ev[slot_stop]));
+  return WM_OK;
+}
+
+// ---- K1 --------------------------------------------------------------------
+int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego,
+                          float* sigma_c, float* yw, int n_planes, int H, int W, int row_stride,
+                          size_t plane_stride, size_t sigma_w_plane_stride, float alpha, int K) {
+  WM_TRY(check_plane_args(ctx, host, n_planes, H, W, row_stride, plane_stride));
+  if (!stego) return set_err(WM_ERR_BADARG, "stego is NULL");
+  if (K < 0 || K > 8) return set_err(WM_ERR_BADARG, "K must be in 0..8");
+  if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
+  const Geom g = make_geom(H, W, row_stride, plane_stride);
+  if (g.n_tiles > 0) {
+    if (!sigma_w || !sigma_c) return set_err(WM_ERR_BADARG, "sigma_w / sigma_c is NULL");
+    if ((((uintptr_t)sigma_w | (uintptr_t)sigma_c) & 15u) || (sigma_w_plane_stride & 3u))
+      return set_err(WM_ERR_BADARG, "sigma arrays must be 16-byte aligned");
+    const bool al = u8_aligned(host, stego, row_stride, plane_stride);
+    const bool vf = yw ? f32_vec_ok(yw, (size_t)W, g.HW) : true;
+    const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+#define WM_LAUNCH_EMBED(A, V)                                                                  \
+  hipLaunchKernelGGL((k_embed_tiles<A, V>), grid, block, 0, ctx->stream, host, sigma_w, stego, \
+                     sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status)
+    if (al && vf) WM_LAUNCH_EMBED(true, true);
+    else if (al) WM_LAUNCH_EMBED(true, false);
+    else if (vf) WM_LAUNCH_EMBED(false, true);
+    else WM_LAUNCH_EMBED(false, false);
+#undef WM_LAUNCH_EMBED
+    WM_HIP(hipGetLastError());
+  }
+  const int Hb = (H / 8) * 8, Wb = (W / 8) * 8;
+  if ((Hb != H || Wb != W) && (stego != host || yw)) {
+    const int n = (W - Wb) * Hb + (H - Hb) * W;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_planes);
+    hipLaunchKernelGGL(k_copy_border, grid, dim3(256), 0, ctx->stream, host, stego, yw, H, W, Hb, Wb,
+                       (size_t)row_stride, plane_stride);
+    WM_HIP(hipGetLastError());
+  }
+  return WM_OK;
+}
+
+// ---- K2 --------------------------------------------------------------------
+int wm_sigma_tiles_u8_dev(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H,
+                          int W, int row_stride, size_t plane_stride) {
+  WM_TRY(check_plane_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
+  const Geom g = make_geom(H, W, row_stride, plane_stride);
+  if (n_planes == 0 || g.n_tiles == 0) return WM_OK;
+  if (!sigma || ((uintptr_t)sigma & 15u)) return set_err(WM_ERR_BADARG, "sigma is NULL or not 16-byte aligned");
+  const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+  if (u8_aligned(planes, planes, row_stride, plane_stride))
+    hipLaunchKernelGGL((k_sigma_tiles<true>), grid, block, 0, ctx->stream, planes, sigma, g, ctx->d_status);
+  else
+    hipLaunchKernelGGL((k_sigma_tiles<false>), grid, block, 0, ctx->stream, planes, sigma, g, ctx->d_status);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+// ---- K3 --------------------------------------------------------------------
+int wm_svd_tiles_f32_dev(wm_ctx* ctx, const float* planes, float* U, float* S, float* Vt,
+                         int n_planes, int H, int W, int row_stride, size_t plane_stride) {
+  WM_TRY(check_plane_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
+  const Geom g = make_geom(H, W, row_stride, plane_stride);
+  if (n_planes == 0 || g.n_tiles == 0) return WM_OK;
+  if (!U || !S || !Vt || (((uintptr_t)U | (uintptr_t)S | (uintptr_t)Vt) & 15u))
+    return set_err(WM_ERR_BADARG, "U/S/Vt is NULL or not 16-byte aligned");
+  const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+  if (f32_vec_ok(planes, (size_t)row_stride, plane_stride))
+    hipLaunchKernelGGL((k_svd_tiles<true>), grid, block, 0, ctx->stream, planes, U, S, Vt, g, ctx->d_status);
+  else
+    hipLaunchKernelGGL((k_svd_tiles<false>), grid, block, 0, ctx->stream, planes, U, S, Vt, g, ctx->d_status);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+// ---- K2+K4 -----------------------------------------------------------------
+int wm_extract_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                            const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                            size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+  WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
+  if (K < 0 || K > 8) return set_err(WM_ERR_BADARG, "K must be in 0..8");
+  if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
+  const Geom g = make_geom(H, W, row_stride, plane_stride);
+  if ((H % 8) || (W % 8))
+    WM_HIP(hipMemsetAsync(out, 0, (size_t)n_planes * g.HW * sizeof(float), ctx->stream));
+  if (g.n_tiles == 0) return WM_OK;
+  if (!sigma_c || !Uw || !Vwt || (((uintptr_t)sigma_c | (uintptr_t)Uw | (uintptr_t)Vwt) & 15u))
+    return set_err(WM_ERR_BADARG, "sigma_c/Uw/Vwt is NULL or not 16-byte aligned");
+  if (uv_plane_stride != 0 && uv_plane_stride != (size_t)g.n_tiles)
+    return set_err(WM_ERR_BADARG, "uv_plane_stride must be 0 (shared) or n_tiles");
+  const float inv_alpha = 1.0f / fmaxf(alpha, 1e-8f);
+  const bool al = u8_aligned(stego, stego, row_stride, plane_stride);
+  const bool vf = f32_vec_ok(out, (size_t)W, g.HW);
+  const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+#define WM_LAUNCH_EXTRACT(A, V)                                                                   \
+  hipLaunchKernelGGL((k_extract_tiles<A, V>), grid, block, 0, ctx->stream, stego, sigma_c, Uw, Vwt, \
+                     out, g, uv_plane_stride, inv_alpha, K, ctx->d_status)
+  if (al && vf) WM_LAUNCH_EXTRACT(true, true);
+  else if (al) WM_LAUNCH_EXTRACT(true, false);
+  else if (vf) WM_LAUNCH_EXTRACT(false, true);
+  else WM_LAUNCH_EXTRACT(false, false);
+#undef WM_LAUNCH_EXTRACT
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+// ---- K4 --------------------------------------------------------------------
+int wm_reconstruct_tiles_dev(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,
+                             float* out, int n_planes, int H, int W) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  if (n_planes < 0 || H < 0 || W < 0 || n_planes > 65535) return set_err(WM_ERR_BADARG, "bad size");
+  if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
+  if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
+  const Geom g = make_geom(H, W, W, (size_t)H * W);
+  if ((H % 8) || (W % 8))
+    WM_HIP(hipMemsetAsync(out, 0, (size_t)n_planes * g.HW * sizeof(float), ctx->stream));
+  if (g.n_tiles == 0) return WM_OK;
+  if (!Uw || !sw_hat || !Vwt || (((uintptr_t)Uw | (uintptr_t)sw_hat | (uintptr_t)Vwt) & 15u))
+    return set_err(WM_ERR_BADARG, "Uw/sw_hat/Vwt is NULL or not 16-byte aligned");
+  const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+  if (f32_vec_ok(out, (size_t)W, g.HW))
+    hipLaunchKernelGGL((k_reconstruct_tiles<true>), grid, block, 0, ctx->stream, Uw, sw_hat, Vwt, out, g);
+  else
+    hipLaunchKernelGGL((k_reconstruct_tiles<false>), grid, block, 0, ctx->stream, Uw, sw_hat, Vwt, out, g);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+// ---- K2+K5 -----------------------------------------------------------------
+int wm_detect_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
+                           const float* sigma_w, double* scores, int n_planes, int H, int W,
+                           int row_stride, size_t plane_stride, size_t sigma_w_plane_stride,
+                           float alpha) {
+  WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!scores) return set_err(WM_ERR_BADARG, "scores is NULL");
+  if (n_planes == 0) return WM_OK;
+  const Geom g = make_geom(H, W, row_stride, plane_stride);
+  const int n_waves = (g.n_tiles + WAVE - 1) / WAVE;
+  if (g.n_tiles > 0) {
+    if (!sigma_c || !sigma_w || (((uintptr_t)sigma_c | (uintptr_t)sigma_w) & 15u) ||
+        (sigma_w_plane_stride & 3u))
+      return set_err(WM_ERR_BADARG, "sigma_c/sigma_w is NULL or not 16-byte aligned");
+    WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes,
+                (size_t)n_planes * n_waves * N_SUMS * sizeof(double), "detect partial sums"));
+    const float inv_alpha = 1.0f / fmaxf(alpha, 1e-8f);
+    const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+    if (u8_aligned(stego, stego, row_stride, plane_stride))
+      hipLaunchKernelGGL((k_detect_tiles<true>), grid, block, 0, ctx->stream, stego, sigma_c, sigma_w,
+                         (double*)ctx->partials, g, sigma_w_plane_stride, inv_alpha, ctx->d_status);
+    else
+      hipLaunchKernelGGL((k_detect_tiles<false>), grid, block, 0, ctx->stream, stego, sigma_c, sigma_w,
+                         (double*)ctx->partials, g, sigma_w_plane_stride, inv_alpha, ctx->d_status);
+    WM_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_detect_finalize, dim3((unsigned)n_planes), dim3(256), 0, ctx->stream,
+                     (const double*)ctx->partials, scores, n_waves, (double)g.n_tiles * 8.0);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+// ===========================================================================
+// host-pointer wrappers: H2D, kernels, D2H, sync.  Convenience for callers
+// without their own device allocator; the throughput path is *_dev.
+// ===========================================================================
+
+int wm_embed_tiles_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego,
+                      float* sigma_c, float* yw, int n_planes, int H, int W, int row_stride,
+                      size_t plane_stride, size_t sigma_w_plane_stride, float alpha, int K) {
+  WM_TRY(check_plane_args(ctx, host, n_planes, H, W, row_stride, plane_stride));
+  if (!stego) return set_err(WM_ERR_BADARG, "stego is NULL");
+  if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
+  const size_t nt = (size_t)(H / 8) * (W / 8);
+  if (nt > 0 && (!sigma_w || !sigma_c)) return set_err(WM_ERR_BADARG, "sigma_w / sigma_c is NULL");
+  const size_t span = plane_span(n_planes, H, row_stride, plane_stride, W);
+  const size_t n_sw = sigma_w_plane_stride ? (size_t)(n_planes - 1) * sigma_w_plane_stride + nt * 8 : nt * 8;
+  const size_t n_sc = (size_t)n_planes * nt * 8;
+  const size_t n_yw = yw ? (size_t)n_planes * H * W : 0;
+  WM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes,
+              2 * pad256(span) + pad256(n_sw * 4) + pad256(n_sc * 4) + pad256(n_yw * 4) + 2048, "scratch"));
+  Carve cv{(char*)ctx->scratch, 0};
+  uint8_t* d_host = cv.take<uint8_t>(span);
+  uint8_t* d_stego = cv.take<uint8_t>(span);
+  float* d_sw = cv.take<float>(n_sw);
+  float* d_sc = cv.take<float>(n_sc);
+  float* d_yw = yw ? cv.take<float>(n_yw) : nullptr;
+  WM_HIP(hipMemcpyAsync(d_host, host, span, hipMemcpyHostToDevice, ctx->stream));
+  // bytes between rows / planes that belong to the caller must survive the round trip
+  if (stego != host) WM_HIP(hipMemcpyAsync(d_stego, stego, span, hipMemcpyHostToDevice, ctx->stream));
+  else d_stego = d_host;
+  if (nt) WM_HIP(hipMemcpyAsync(d_sw, sigma_w, n_sw * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_TRY(wm_embed_tiles_u8_dev(ctx, d_host, d_sw, d_stego, d_sc, d_yw, n_planes, H, W, row_stride,
+                               plane_stride, sigma_w_plane_stride, alpha, K));
+  WM_HIP(hipMemcpyAsync(stego, d_stego, span, hipMemcpyDeviceToHost, ctx->stream));
+  if (nt) WM_HIP(hipMemcpyAsync(sigma_c, d_sc, n_sc * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (yw) WM_HIP(hipMemcpyAsync(yw, d_yw, n_yw * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return wm_check_status(ctx);
+}
+
+int wm_sigma_tiles_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H, int W,
+                      int row_stride, size_t plane_stride) {
+  WM_TRY(check_plane_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
+  const size_t nt = (size_t)(H / 8) * (W / 8);
+  if (n_planes == 0 || nt == 0) return WM_OK;
+  if (!sigma) return set_err(WM_ERR_BADARG, "sigma is NULL");
+  const size_t span = plane_span(n_planes, H, row_stride, plane_stride, W);
+  const size_t n_s = (size_t)n_planes * nt * 8;
+  WM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes, pad256(span) + pad256(n_s * 4) + 1024, "scratch"));
+  Carve cv{(char*)ctx->scratch, 0};
+  uint8_t* d_p = cv.take<uint8_t>(span);
+  float* d_s = cv.take<float>(n_s);
+  WM_HIP(hipMemcpyAsync(d_p, planes, span, hipMemcpyHostToDevice, ctx->stream));
+  WM_TRY(wm_sigma_tiles_u8_dev(ctx, d_p, d_s, n_planes, H, W, row_stride, plane_stride));
+  WM_HIP(hipMemcpyAsync(sigma, d_s, n_s * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return wm_check_status(ctx);
+}
+
+int wm_svd_tiles_f32(wm_ctx* ctx, const float* planes, float* U, float* S, float* Vt, int n_planes,
+                     int H, int W, int row_stride, size_t plane_stride) {
+  WM_TRY(check_plane_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
+  const size_t nt = (size_t)(H / 8) * (W / 8);
+  if (n_planes == 0 || nt == 0) return WM_OK;
+  if (!U || !S || !Vt) return set_err(WM_ERR_BADARG, "U/S/Vt is NULL");
+  const size_t span = plane_span(n_planes, H, row_stride, plane_stride, W);
+  const size_t n_m = (size_t)n_planes * nt * 64, n_s = (size_t)n_planes * nt * 8;
+  WM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes,
+              pad256(span * 4) + 2 * pad256(n_m * 4) + pad256(n_s * 4) + 2048, "scratch"));
+  Carve cv{(char*)ctx->scratch, 0};
+  float* d_p = cv.take<float>(span);
+  float* d_U = cv.take<float>(n_m);
+  float* d_V = cv.take<float>(n_m);
+  float* d_S = cv.take<float>(n_s);
+  WM_HIP(hipMemcpyAsync(d_p, planes, span * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_TRY(wm_svd_tiles_f32_dev(ctx, d_p, d_U, d_S, d_V, n_planes, H, W, row_stride, plane_stride));
+  WM_HIP(hipMemcpyAsync(U, d_U, n_m * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipMemcpyAsync(Vt, d_V, n_m * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipMemcpyAsync(S, d_S, n_s * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return wm_check_status(ctx);
+}
+
+int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                        const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                        size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+  WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
+  if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
+  const size_t nt = (size_t)(H / 8) * (W / 8);
+  if (nt > 0 && (!sigma_c || !Uw || !Vwt)) return set_err(WM_ERR_BADARG, "sigma_c/Uw/Vwt is NULL");
+  const size_t span = plane_span(n_planes, H, row_stride, plane_stride, W);
+  const size_t n_sc = (size_t)n_planes * nt * 8;
+  const size_t n_uv = (uv_plane_stride ? (size_t)n_planes : (size_t)1) * nt * 64;
+  const size_t n_out = (size_t)n_planes * H * W;
+  WM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes,
+              pad256(span) + pad256(n_sc * 4) + 2 * pad256(n_uv * 4) + pad256(n_out * 4) + 2048, "scratch"));
+  Carve cv{(char*)ctx->scratch, 0};
+  uint8_t* d_p = cv.take<uint8_t>(span);
+  float* d_sc = cv.take<float>(n_sc);
+  float* d_U = cv.take<float>(n_uv);
+  float* d_V = cv.take<float>(n_uv);
+  float* d_o = cv.take<float>(n_out);
+  WM_HIP(hipMemcpyAsync(d_p, stego, span, hipMemcpyHostToDevice, ctx->stream));
+  if (nt) {
+    WM_HIP(hipMemcpyAsync(d_sc, sigma_c, n_sc * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemcpyAsync(d_U, Uw, n_uv * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemcpyAsync(d_V, Vwt, n_uv * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  WM_TRY(wm_extract_tiles_u8_dev(ctx, d_p, d_sc, d_U, d_V, d_o, n_planes, H, W, row_stride, plane_stride,
+                                 uv_plane_stride, alpha, K));
+  WM_HIP(hipMemcpyAsync(out, d_o, n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return wm_check_status(ctx);
+}
+
+int wm_reconstruct_tiles(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,
+                         float* out, int n_planes, int H, int W) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  if (n_planes < 0 || H < 0 || W < 0) return set_err(WM_ERR_BADARG, "negative size");
+  if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
+  if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
+  const size_t nt = (size_t)(H / 8) * (W / 8);
+  if (nt > 0 && (!Uw || !sw_hat || !Vwt)) return set_err(WM_ERR_BADARG, "Uw/sw_hat/Vwt is NULL");
+  const size_t n_m = (size_t)n_planes * nt * 64, n_s = (size_t)n_planes * nt * 8;
+  const size_t n_out = (size_t)n_planes * H * W;
+  WM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes,
+              2 * pad256(n_m * 4) + pad256(n_s * 4) + pad256(n_out * 4) + 2048, "scratch"));
+  Carve cv{(char*)ctx->scratch, 0};
+  float* d_U = cv.take<float>(n_m);
+  float* d_V = cv.take<float>(n_m);
+  float* d_s = cv.take<float>(n_s);
+  float* d_o = cv.take<float>(n_out);
+  if (nt) {
+    WM_HIP(hipMemcpyAsync(d_U, Uw, n_m * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemcpyAsync(d_V, Vwt, n_m * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemcpyAsync(d_s, sw_hat, n_s * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  WM_TRY(wm_reconstruct_tiles_dev(ctx, d_U, d_s, d_V, d_o, n_planes, H, W));
+  WM_HIP(hipMemcpyAsync(out, d_o, n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+int wm_detect_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
+                       double* scores, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                       size_t sigma_w_plane_stride, float alpha) {
+  WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!scores) return set_err(WM_ERR_BADARG, "scores is NULL");
+  if (n_planes == 0) return WM_OK;
+  const size_t nt = (size_t)(H / 8) * (W / 8);
+  if (nt > 0 && (!sigma_c || !sigma_w)) return set_err(WM_ERR_BADARG, "sigma_c/sigma_w is NULL");
+  const size_t span = plane_span(n_planes, H, row_stride, plane_stride, W);
+  const size_t n_sc = (size_t)n_planes * nt * 8;
+  const size_t n_sw = sigma_w_plane_stride ? (size_t)(n_planes - 1) * sigma_w_plane_stride + nt * 8 : nt * 8;
+  WM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes,
+              pad256(span) + pad256(n_sc * 4) + pad256(n_sw * 4) + pad256((size_t)n_planes * 8) + 2048,
+              "scratch"));
+  Carve cv{(char*)ctx->scratch, 0};
+  uint8_t* d_p = cv.take<uint8_t>(span ? span : 1);
+  float* d_sc = cv.take<float>(n_sc);
+  float* d_sw = cv.take<float>(n_sw);
+  double* d_scores = cv.take<double>((size_t)n_planes);
+  if (span) WM_HIP(hipMemcpyAsync(d_p, stego, span, hipMemcpyHostToDevice, ctx->stream));
+  if (nt) {
+    WM_HIP(hipMemcpyAsync(d_sc, sigma_c, n_sc * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemcpyAsync(d_sw, sigma_w, n_sw * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  WM_TRY(wm_detect_tiles_u8_dev(ctx, d_p, d_sc, d_sw, d_scores, n_planes, H, W, row_stride, plane_stride,
+                                sigma_w_plane_stride, alpha));
+  WM_HIP(hipMemcpyAsync(scores, d_scores, (size_t)n_planes * 8, hipMemcpyDeviceToHost, ctx->stream));
+  return wm_check_status(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+"""ctypes binding of libwmhip.so (include/wmhip.h) - the thin Python side of
+the C ABI.  No CPU fallback: if the HIP library is missing or there is no GPU,
+calls raise (``WmLibraryError`` / ``WmError``) instead of computing anything
+on the host.
+
+The error mapping mirrors what the reference's callers see
+(app_dct_svd_single.py:115-116,208-209, numpy LinAlgError):
+  WM_ERR_BADARG -> ValueError, WM_ERR_NOCONV -> numpy.linalg.LinAlgError,
+  WM_ERR_NOMEM  -> MemoryError, WM_ERR_HIP -> WmError (RuntimeError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+WM_OK, WM_ERR_BADARG, WM_ERR_HIP, WM_ERR_NOCONV, WM_ERR_NOMEM = 0, 1, 2, 3, 4
+TILE = 8
+ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwmhip.so")
+
+
+class WmLibraryError(ImportError):
+    """libwmhip.so is not built / not loadable."""
+
+
+class WmError(RuntimeError):
+    """A HIP runtime call inside libwmhip.so failed."""
+
+
+_lib = None
+
+_sz = C.c_size_t
+_vp = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+# name -> argtypes  (every symbol include/wmhip.h declares)
+SIGNATURES = {
+    "wm_abi_version": [],
+    "wm_last_error": [],
+    "wm_device_count": [C.POINTER(_i)],
+    "wm_create": [_i, _vp, C.POINTER(_vp)],
+    "wm_destroy": [_vp],
+    "wm_sync": [_vp],
+    "wm_check_status": [_vp],
+    "wm_malloc": [_vp, _sz, C.POINTER(_vp)],
+    "wm_free": [_vp, _vp],
+    "wm_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "wm_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "wm_memset": [_vp, _vp, _i, _sz],
+    "wm_event_record": [_vp, _i],
+    "wm_event_elapsed_ms": [_vp, _i, _i, C.POINTER(_f)],
+    "wm_embed_tiles_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_embed_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_sigma_tiles_u8_dev": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
+    "wm_sigma_tiles_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
+    "wm_svd_tiles_f32_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz],
+    "wm_svd_tiles_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz],
+    "wm_extract_tiles_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_extract_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_reconstruct_tiles_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "wm_reconstruct_tiles": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "wm_detect_tiles_u8_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f],
+    "wm_detect_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f],
+}
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libwmhip.so and type every entry point.  Raises WmLibraryError -
+    never falls back to a host implementation."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise WmLibraryError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise WmLibraryError(f"cannot load {p}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the ABI drifted
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "wm_last_error" else _i
+    if lib.wm_abi_version() != ABI_VERSION:
+        raise WmLibraryError(f"ABI version mismatch: library {lib.wm_abi_version()} != binding {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _raise(lib, rc: int):
+    msg = (lib.wm_last_error() or b"").decode("utf-8", "replace")
+    if rc == WM_ERR_BADARG:
+        raise ValueError(msg)
+    if rc == WM_ERR_NOCONV:
+        raise np.linalg.LinAlgError(msg)
+    if rc == WM_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise WmError(f"[{rc}] {msg}")
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = _i(0)
+    rc = lib.wm_device_count(C.byref(n))
+    if rc:
+        _raise(lib, rc)
+    return n.value
+
+
+def _ptr(x) -> Optional[int]:
+    """numpy array -> host address; int -> passed through (device pointer)."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return int(x)
+
+
+def _plane_layout(a: np.ndarray):
+    """(n_planes, H, W, row_stride, plane_stride) in elements of a [H,W] or
+    [N,H,W] array whose last axis is contiguous."""
+    if a.ndim == 2:
+        a = a[None]
+    if a.ndim != 3:
+        raise ValueError("planes must be [H, W] or [n_planes, H, W]")
+    n, H, W = a.shape
+    it = a.itemsize
+    if W and a.strides[2] != it:
+        raise ValueError("last axis must be contiguous")
+    rs = a.strides[1] // it if H > 1 else max(W, a.strides[1] // it if a.strides[1] else W)
+    ps = a.strides[0] // it if n > 1 else rs * H
+    return n, H, W, max(rs, W), ps
+
+
+class Context:
+    """One device + one HIP stream (wm_ctx).  ``stream`` may be a raw
+    hipStream_t handle (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.wm_create(device, _vp(stream) if stream else None, C.byref(h))
+        if rc:
+            _raise(self.lib, rc)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.wm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self._h, *args)
+        if rc:
+            _raise(self.lib, rc)
+
+    # ---- plumbing -------------------------------------------------------
+    def sync(self):
+        self._call("wm_sync")
+
+    def check_status(self):
+        self._call("wm_check_status")
+
+    def malloc(self, nbytes: int) -> int:
+        p = _vp()
+        self._call("wm_malloc", nbytes, C.byref(p))
+        return p.value
+
+    def free(self, dptr: int):
+        self._call("wm_free", _vp(dptr))
+
+    def h2d(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._call("wm_memcpy_h2d", _vp(dptr), _vp(arr.ctypes.data), arr.nbytes)
+        self.sync()
+
+    def d2h(self, arr: np.ndarray, dptr: int):
+        assert arr.flags.c_contiguous
+        self._call("wm_memcpy_d2h", _vp(arr.ctypes.data), _vp(dptr), arr.nbytes)
+
+    def memset(self, dptr: int, value: int, nbytes: int):
+        self._call("wm_memset", _vp(dptr), value, nbytes)
+
+    def event_record(self, slot: int):
+        self._call("wm_event_record", slot)
+
+    def event_elapsed_ms(self, a: int, b: int) -> float:
+        ms = _f(0)
+        self._call("wm_event_elapsed_ms", a, b, C.byref(ms))
+        return ms.value
+
+    # ---- device-pointer entry points (ints are device addresses) ---------
+    def embed_tiles_u8_dev(self, host, sigma_w, stego, sigma_c, yw, n_planes, H, W, row_stride,
+                           plane_stride, sigma_w_plane_stride, alpha, K):
+        self._call("wm_embed_tiles_u8_dev", _vp(host), _vp(sigma_w), _vp(stego), _vp(sigma_c),
+                   _vp(yw) if yw else None, n_planes, H, W, row_stride, plane_stride,
+                   sigma_w_plane_stride, alpha, K)
+
+    def sigma_tiles_u8_dev(self, planes, sigma, n_planes, H, W, row_stride, plane_stride):
+        self._call("wm_sigma_tiles_u8_dev", _vp(planes), _vp(sigma), n_planes, H, W, row_stride, plane_stride)
+
+    def svd_tiles_f32_dev(self, planes, U, S, Vt, n_planes, H, W, row_stride, plane_stride):
+        self._call("wm_svd_tiles_f32_dev", _vp(planes), _vp(U), _vp(S), _vp(Vt), n_planes, H, W,
+                   row_stride, plane_stride)
+
+    def extract_tiles_u8_dev(self, stego, sigma_c, Uw, Vwt, out, n_planes, H, W, row_stride,
+                             plane_stride, uv_plane_stride, alpha, K):
+        self._call("wm_extract_tiles_u8_dev", _vp(stego), _vp(sigma_c), _vp(Uw), _vp(Vwt), _vp(out),
+                   n_planes, H, W, row_stride, plane_stride, uv_plane_stride, alpha, K)
+
+    def reconstruct_tiles_dev(self, Uw, sw_hat, Vwt, out, n_planes, H, W):
+        self._call("wm_reconstruct_tiles_dev", _vp(Uw), _vp(sw_hat), _vp(Vwt), _vp(out), n_planes, H, W)
+
+    def detect_tiles_u8_dev(self, stego, sigma_c, sigma_w, scores, n_planes, H, W, row_stride,
+                            plane_stride, sigma_w_plane_stride, alpha):
+        self._call("wm_detect_tiles_u8_dev", _vp(stego), _vp(sigma_c), _vp(sigma_w), _vp(scores),
+                   n_planes, H, W, row_stride, plane_stride, sigma_w_plane_stride, alpha)
+
+    # ---- NumPy (host-buffer) entry points --------------------------------
+    def embed_tiles(self, host: np.ndarray, sigma_w: np.ndarray, alpha: float, K: int = 8,
+                    want_yw: bool = False):
+        """host uint8 [H,W] or [N,H,W]; sigma_w float32 [nby,nbx,8] (shared) or
+        [N,nby,nbx,8].  Returns (stego uint8, sigma_c float32 [N?,nby,nbx,8], yw or None)."""
+        if host.dtype != np.uint8:
+            raise ValueError("host planes must be uint8")
+        n, H, W, rs, ps = _plane_layout(host)
+        nby, nbx = H // TILE, W // TILE
+        sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
+        per_plane = sw.ndim == 4
+        if sw.shape[-3:] != (nby, nbx, 8) or (per_plane and sw.shape[0] != n):
+            raise ValueError(f"sigma_w shape {sw.shape} does not match {n}x{nby}x{nbx}x8")
+        stego = np.empty((n, H, W), np.uint8)
+        sc = np.empty((n, nby, nbx, 8), np.float32)
+        yw = np.empty((n, H, W), np.float32) if want_yw else None
+        # stego is dense; host may be strided -> densify so both share one layout
+        hostc = np.ascontiguousarray(host.reshape(n, H, W))
+        self._call("wm_embed_tiles_u8", _vp(hostc.ctypes.data), _vp(sw.ctypes.data), _vp(stego.ctypes.data),
+                   _vp(sc.ctypes.data), _vp(yw.ctypes.data) if want_yw else None, n, H, W, W, H * W,
+                   nby * nbx * 8 if per_plane else 0, float(alpha), int(K))
+        if host.ndim == 2:
+            return stego[0], sc[0], (yw[0] if want_yw else None)
+        return stego, sc, yw
+
+    def sigma_tiles(self, planes: np.ndarray) -> np.ndarray:
+        if planes.dtype != np.uint8:
+            raise ValueError("planes must be uint8")
+        n, H, W, rs, ps = _plane_layout(planes)
+        s = np.empty((n, H // TILE, W // TILE, 8), np.float32)
+        self._call("wm_sigma_tiles_u8", _vp(planes.ctypes.data), _vp(s.ctypes.data), n, H, W, rs, ps)
+        return s[0] if planes.ndim == 2 else s
+
+    def svd_tiles(self, planes: np.ndarray):
+        """float32 planes -> (U [..,nby,nbx,8,8], S [..,nby,nbx,8], Vt [..,nby,nbx,8,8])."""
+        if planes.dtype != np.float32:
+            raise ValueError("planes must be float32")
+        n, H, W, rs, ps = _plane_layout(planes)
+        nby, nbx = H // TILE, W // TILE
+        U = np.empty((n, nby, nbx, 8, 8), np.float32)
+        S = np.empty((n, nby, nbx, 8), np.float32)
+        Vt = np.empty((n, nby, nbx, 8, 8), np.float32)
+        self._call("wm_svd_tiles_f32", _vp(planes.ctypes.data), _vp(U.ctypes.data), _vp(S.ctypes.data),
+                   _vp(Vt.ctypes.data), n, H, W, rs, ps)
+        if planes.ndim == 2:
+            return U[0], S[0], Vt[0]
+        return U, S, Vt
+
+    def extract_tiles(self, stego: np.ndarray, sigma_c: np.ndarray, Uw: np.ndarray, Vwt: np.ndarray,
+                      alpha: float, K: int = 8) -> np.ndarray:
+        if stego.dtype != np.uint8:
+            raise ValueError("stego planes must be uint8")
+        n, H, W, rs, ps = _plane_layout(stego)
+        nby, nbx = H // TILE, W // TILE
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32).reshape(n, nby, nbx, 8)
+        Uw = np.ascontiguousarray(Uw, dtype=np.float32)
+        Vwt = np.ascontiguousarray(Vwt, dtype=np.float32)
+        per_plane = Uw.ndim == 5
+        if Uw.shape[-4:] != (nby, nbx, 8, 8) or Vwt.shape != Uw.shape:
+            raise ValueError("Uw/Vwt shape mismatch")
+        out = np.empty((n, H, W), np.float32)
+        self._call("wm_extract_tiles_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
+                   _vp(Vwt.ctypes.data), _vp(out.ctypes.data), n, H, W, rs, ps,
+                   nby * nbx if per_plane else 0, float(alpha), int(K))
+        return out[0] if stego.ndim == 2 else out
+
+    def reconstruct_tiles(self, Uw: np.ndarray, sw_hat: np.ndarray, Vwt: np.ndarray, H: int, W: int):
+        Uw = np.ascontiguousarray(Uw, dtype=np.float32)
+        Vwt = np.ascontiguousarray(Vwt, dtype=np.float32)
+        sh = np.ascontiguousarray(sw_hat, dtype=np.float32)
+        single = Uw.ndim == 4
+        n = 1 if single else Uw.shape[0]
+        out = np.empty((n, H, W), np.float32)
+        self._call("wm_reconstruct_tiles", _vp(Uw.ctypes.data), _vp(sh.ctypes.data), _vp(Vwt.ctypes.data),
+                   _vp(out.ctypes.data), n, H, W)
+        return out[0] if single else out
+
+    def detect_tiles(self, stego: np.ndarray, sigma_c: np.ndarray, sigma_w: np.ndarray,
+                     alpha: float) -> np.ndarray:
+        if stego.dtype != np.uint8:
+            raise ValueError("stego planes must be uint8")
+        n, H, W, rs, ps = _plane_layout(stego)
+        nby, nbx = H // TILE, W // TILE
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32).reshape(n, nby, nbx, 8)
+        sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
+        per_plane = sw.ndim == 4
+        scores = np.zeros(n, np.float64)
+        self._call("wm_detect_tiles_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
+                   _vp(scores.ctypes.data), n, H, W, rs, ps, nby * nbx * 8 if per_plane else 0, float(alpha))
+        return scores

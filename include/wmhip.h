@@ -1,0 +1,158 @@
+/* wmhip.h - C ABI of the MI355X (gfx950) DCT-SVD watermark hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (Thitrongdan202/Digital-Watermarking-...-DCT-SVD) has no FFI seam: its hot
+ * path is ~12 inline NumPy/OpenCV statements per branch inside
+ * embed/extract/detect of app_dct_svd_single.py.  Each entry point below names
+ * the reference statements (file:line, "single" = app_dct_svd_single.py,
+ * "core" = dct_svd_core_secure.py) it replaces when those are applied to every
+ * 8x8 tile of a plane ("tile-mode").  The binding a
+ * maintainer would add on the reference side is a ctypes stub - see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, caller-owned buffers, nothing retained between calls;
+ *  - every function returns an int status (WM_OK == 0); wm_last_error() gives
+ *    the message for the calling thread;
+ *  - a wm_ctx binds one device + one HIP stream; two contexts are independently
+ *    usable from two threads;
+ *  - *_dev entry points take DEVICE pointers, enqueue on the context's stream
+ *    and return without synchronising; the un-suffixed ones take HOST pointers
+ *    and do H2D + kernels + D2H + sync themselves;
+ *  - planes are row-major uint8 (or float32) with `row_stride` in ELEMENTS
+ *    between rows and `plane_stride` in ELEMENTS between planes; tiles are
+ *    numbered t = ty * (W/8) + tx; per-tile arrays are tile-major:
+ *    sigma[plane][t][8], U[plane][t][8][8] (row, col), Vt[plane][t][8][8].
+ *  - rows/columns beyond the last full tile (H % 8, W % 8) are passed through
+ *    unchanged by embed and written as 0 by extract/reconstruct.
+ */
+#ifndef WMHIP_H
+#define WMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_OK 0
+#define WM_ERR_BADARG 1   /* NULL pointer, non-positive size, K outside 0..8 ...      */
+#define WM_ERR_HIP 2      /* a HIP runtime call failed; wm_last_error() has the text  */
+#define WM_ERR_NOCONV 3   /* Jacobi hit its sweep bound (numpy: LinAlgError)          */
+#define WM_ERR_NOMEM 4    /* device or host allocation failed                         */
+
+#define WM_TILE 8
+#define WM_ABI_VERSION 1
+
+typedef struct wm_ctx wm_ctx;
+
+/* ---- library / context ------------------------------------------------- */
+int wm_abi_version(void);
+const char* wm_last_error(void);
+int wm_device_count(int* n_out);
+/* stream == NULL: the context creates (and owns) a non-blocking stream.
+ * Otherwise `stream` is a hipStream_t the caller owns (e.g. torch's current
+ * stream handle) and all work is enqueued there. */
+int wm_create(int device, void* stream, wm_ctx** ctx_out);
+int wm_destroy(wm_ctx* ctx);
+int wm_sync(wm_ctx* ctx);
+/* Reads-and-clears the sticky kernel status word (synchronises the stream):
+ * WM_OK or WM_ERR_NOCONV. */
+int wm_check_status(wm_ctx* ctx);
+
+/* device memory + copies for callers that do not bring their own allocator */
+int wm_malloc(wm_ctx* ctx, size_t bytes, void** dptr_out);
+int wm_free(wm_ctx* ctx, void* dptr);
+int wm_memcpy_h2d(wm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int wm_memcpy_d2h(wm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int wm_memset(wm_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* HIP-event timing on the context's stream (slot 0..15) */
+int wm_event_record(wm_ctx* ctx, int slot);
+int wm_event_elapsed_ms(wm_ctx* ctx, int slot_start, int slot_stop, float* ms_out);
+
+/* ---- K1: fused tile-mode embed ------------------------------------------
+ * Replaces, per 8x8 tile:  .astype(float32) (single:24,122) -> dct2
+ * (single:32-33,172) -> np.linalg.svd (single:172) -> S_[:K] = Sc[:K] +
+ * alpha*Sw[:K] (single:174-175) -> Uc @ diag(S_) @ Vct (single:176) -> idct2
+ * (single:177) -> np.clip(.,0,255).astype(uint8) (single:27,145-147).
+ *   host     [n_planes] uint8 planes (in)
+ *   sigma_w  watermark singular values [.. n_tiles][8]; plane p reads
+ *            sigma_w + p * sigma_w_plane_stride (0 => one set shared by all
+ *            planes: the "watermark S computed once per video" shape)
+ *   stego    [n_planes] uint8 planes (out; may alias host)
+ *   sigma_c  [n_planes][n_tiles][8] host singular values "Sc" (out, for meta)
+ *   yw       optional [n_planes][H][W] float32 unclipped stego (what gray-mode
+ *            SSIM consumes, single:190); NULL to skip
+ *   K        number of leading singular values perturbed, 0..8
+ *            (reference: K = max(8, int(kfrac*8)) = 8). */
+int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w,
+                          uint8_t* stego, float* sigma_c, float* yw,
+                          int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                          size_t sigma_w_plane_stride, float alpha, int K);
+int wm_embed_tiles_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w,
+                      uint8_t* stego, float* sigma_c, float* yw,
+                      int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                      size_t sigma_w_plane_stride, float alpha, int K);
+
+/* ---- K2: singular values of every tile of a uint8 plane ------------------
+ * Replaces  Cw = dct2(Y); _, S_cw, _ = np.linalg.svd(Cw)  (single:205,
+ * 234-236, 297, 305-307) per tile.  sigma: [n_planes][n_tiles][8]. */
+int wm_sigma_tiles_u8_dev(wm_ctx* ctx, const uint8_t* planes, float* sigma,
+                          int n_planes, int H, int W, int row_stride, size_t plane_stride);
+int wm_sigma_tiles_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma,
+                      int n_planes, int H, int W, int row_stride, size_t plane_stride);
+
+/* ---- K3: full SVD of every tile of a float32 plane (watermark side) ------
+ * Replaces  Wm = dct2(wy_s); Uw, Sw, Vwt = np.linalg.svd(Wm)  (single:173,
+ * 131-134) per tile.  U, Vt: [n_planes][n_tiles][8][8]; S: [..][8]. */
+int wm_svd_tiles_f32_dev(wm_ctx* ctx, const float* planes, float* U, float* S, float* Vt,
+                         int n_planes, int H, int W, int row_stride, size_t plane_stride);
+int wm_svd_tiles_f32(wm_ctx* ctx, const float* planes, float* U, float* S, float* Vt,
+                     int n_planes, int H, int W, int row_stride, size_t plane_stride);
+
+/* ---- K2+K4: fused tile-mode extract --------------------------------------
+ * Replaces, per tile:  dct2 + svd of the stego (single:205) ->
+ * Sw_hat = (S_cw - Sc) / max(alpha,1e-8); Sw_hat[K:] = 0 (single:212-213) ->
+ * Uw @ diag(Sw_hat) @ Vwt (single:214) -> idct2 (single:218).
+ *   sigma_c  [n_planes][n_tiles][8]
+ *   Uw, Vwt  [..][n_tiles][8][8]; plane p reads + p * uv_plane_stride
+ *            (0 => shared by all planes)
+ *   out      [n_planes][H][W] float32 scrambled-watermark estimate wy_s
+ *            (dense, row stride W) - input of _unpermute (single:220). */
+int wm_extract_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
+                            const float* Uw, const float* Vwt, float* out,
+                            int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                            size_t uv_plane_stride, float alpha, int K);
+int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
+                        const float* Uw, const float* Vwt, float* out,
+                        int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                        size_t uv_plane_stride, float alpha, int K);
+
+/* ---- K4: Uw diag(sw_hat) Vwt + idct2 per tile (single:214-218) ----------- */
+int wm_reconstruct_tiles_dev(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,
+                             float* out, int n_planes, int H, int W);
+int wm_reconstruct_tiles(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,
+                         float* out, int n_planes, int H, int W);
+
+/* ---- K2+K5: fused tile-mode detect ---------------------------------------
+ * Replaces  svd of the stego (single:297) -> Sw_hat = (S_cw - Sc)/max(alpha,
+ * 1e-8) over ALL singular values (single:300) -> _nc(Sw, Sw_hat)
+ * (single:284-289, 301) with the vectors flattened over all tiles.
+ *   scores   [n_planes] float64 normalised-correlation score per plane
+ *            (device pointer for _dev).  The caller applies  score >= thresh
+ *            and the 3-plane mean of colour mode (single:302, 317-318). */
+int wm_detect_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
+                           const float* sigma_w, double* scores,
+                           int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                           size_t sigma_w_plane_stride, float alpha);
+int wm_detect_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
+                       const float* sigma_w, double* scores,
+                       int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                       size_t sigma_w_plane_stride, float alpha);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMHIP_H */

@@ -1,0 +1,107 @@
+"""GPU parity: HIP tile-mode kernels (through the C ABI) vs the NumPy oracle.
+
+Tolerances (BASELINE.json north_star): singular values within 1e-4 relative
+(to sigma_1 of the tile), uint8 stego within 1 LSB."""
+import numpy as np
+import pytest
+
+from oracle import wm_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+SIGMA_RTOL = 1e-4
+
+
+def _inputs(H, W, seed=1234, wseed=4321):
+    host = np.random.default_rng(seed).integers(0, 256, (H, W), dtype=np.uint8)
+    wm = np.random.default_rng(wseed).integers(0, 256, (H, W), dtype=np.uint8)
+    key = o.derive_key("bench", bytes(8))
+    idx = o.permutation(H, W, o.rng_from_key(key))
+    return host, o.permute(wm.astype(np.float32), idx)
+
+
+def _rel_sigma(a, b):
+    a = a.reshape(-1, 8); b = b.reshape(-1, 8)
+    return float(np.max(np.abs(a - b) / np.maximum(b[:, :1], 1e-30)))
+
+
+@pytest.mark.parametrize("H,W", [(8, 8), (64, 96), (512, 512), (1080, 1920)])
+def test_embed_parity(gpu_ctx, H, W):
+    alpha = 0.15
+    host, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, tile=8)
+    stego, sc, yw = gpu_ctx.embed_tiles(host, ref["Sw"], alpha, K=8, want_yw=True)
+    assert _rel_sigma(sc, ref["Sc"]) < SIGMA_RTOL
+    d = np.abs(stego.astype(np.int32) - ref["stego"].astype(np.int32))
+    assert d.max() <= 1
+    assert np.mean(d != 0) < 2e-3          # truncation flips only where Yw sits on an integer
+    assert np.abs(yw - ref["Yw"]).max() < 5e-3
+    assert abs(o.psnr(host, stego) - o.psnr(host, ref["stego"])) < 1e-3
+
+
+def test_svd_tiles_parity(gpu_ctx):
+    H, W = 256, 320
+    _, wys = _inputs(H, W)
+    U, S, Vt = gpu_ctx.svd_tiles(wys)
+    Uo, So, Vto = o.watermark_decompose(wys, 8)
+    assert _rel_sigma(S, So) < SIGMA_RTOL
+    # singular vectors are sign-ambiguous: compare the rank-1 terms
+    rec = np.matmul(U * S[..., None, :], Vt)
+    reco = np.matmul(Uo * So[..., None, :], Vto)
+    assert np.abs(rec - reco).max() < 5e-3
+    I = np.eye(8, dtype=np.float32)
+    assert np.abs(np.matmul(U.swapaxes(-1, -2), U) - I).max() < 1e-5
+    assert np.abs(np.matmul(Vt, Vt.swapaxes(-1, -2)) - I).max() < 1e-5
+    assert np.all(np.diff(S, axis=-1) <= 1e-3 * S[..., :1])   # descending like LAPACK
+
+
+@pytest.mark.parametrize("K", [8, 3])
+def test_sigma_extract_detect_parity(gpu_ctx, K):
+    H, W, alpha = 512, 512, 0.15
+    host, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, tile=8, k_floor=K, kfrac=0.0)
+    st = ref["stego"]
+    s = gpu_ctx.sigma_tiles(st)
+    assert _rel_sigma(s, o.stego_sigma(st.astype(np.float32), 8)) < SIGMA_RTOL
+    w = gpu_ctx.extract_tiles(st, ref["Sc"], ref["Uw"], ref["Vwt"], alpha, K=K)
+    wo = o.extract_plane(st.astype(np.float32), ref["Sc"], ref["Uw"], ref["Vwt"], alpha, 0.0, H, W, 8, k_floor=K)
+    assert np.abs(w - wo).max() < 2e-2          # values span ~[-300, 300]
+    score = gpu_ctx.detect_tiles(st, ref["Sc"], ref["Sw"], alpha)[0]
+    assert abs(score - o.detect_plane(st.astype(np.float32), ref["Sc"], ref["Sw"], alpha, 8)) < 1e-4
+    clean = gpu_ctx.detect_tiles(host, ref["Sc"], ref["Sw"], alpha)[0]
+    assert abs(clean) < 1e-6 and score > 0.9
+
+
+def test_ragged_and_batched(gpu_ctx):
+    """H, W not multiples of 8: border passes through embed and reads 0 in
+    extract; batched planes with a shared sigma_w."""
+    H, W, alpha = 45, 70, 0.12
+    rng = np.random.default_rng(7)
+    hosts = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+    Uo, So, Vto = o.watermark_decompose(wys, 8)
+    stego, sc, yw = gpu_ctx.embed_tiles(hosts, So, alpha, want_yw=True)
+    for p in range(3):
+        ref = o.embed_plane(hosts[p].astype(np.float32), wys, alpha, 0.6, 8, wm_svd=(Uo, So, Vto))
+        assert np.abs(stego[p].astype(int) - ref["stego"].astype(int)).max() <= 1
+        assert np.array_equal(stego[p][40:, :], hosts[p][40:, :])
+        assert np.array_equal(stego[p][:, 64:], hosts[p][:, 64:])
+        assert _rel_sigma(sc[p], ref["Sc"]) < SIGMA_RTOL
+    w = gpu_ctx.extract_tiles(stego, sc, Uo, Vto, alpha)
+    assert np.all(w[:, 40:, :] == 0) and np.all(w[:, :, 64:] == 0)
+    wo = o.extract_plane(stego[1].astype(np.float32), sc[1], Uo, Vto, alpha, 0.6, H, W, 8)
+    assert np.abs(w[1] - wo).max() < 2e-2
+
+
+def test_empty_and_bad_args(gpu_ctx):
+    z = np.zeros((0, 0), np.uint8)
+    st, sc, _ = gpu_ctx.embed_tiles(z, np.zeros((0, 0, 8), np.float32), 0.1)
+    assert st.shape == (0, 0)
+    small = np.full((5, 7), 9, np.uint8)          # no full tile: pure pass-through
+    st, sc, _ = gpu_ctx.embed_tiles(small, np.zeros((0, 0, 8), np.float32), 0.1)
+    assert np.array_equal(st, small) and sc.size == 0
+    assert gpu_ctx.detect_tiles(small, np.zeros((0, 0, 8), np.float32), np.zeros((0, 0, 8), np.float32), 0.1)[0] == 0.0
+    with pytest.raises(ValueError):
+        gpu_ctx.embed_tiles(np.zeros((8, 8), np.uint8), np.zeros((1, 1, 8), np.float32), 0.1, K=9)
+    with pytest.raises(ValueError):
+        gpu_ctx.embed_tiles(np.zeros((8, 8), np.float32), np.zeros((1, 1, 8), np.float32), 0.1)

@@ -1,0 +1,63 @@
+"""Quick device-resident timing of the tile kernels (no torch): HIP events on the
+context's stream around repeated launches.  Development aid; bench.py is the
+contract benchmark."""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+api = importlib.import_module(
+    "digital-watermarking-for-image-video-using-dct-svd-singular-value-decomposition_amd.hostapi")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--H", type=int, default=2160)
+    ap.add_argument("--W", type=int, default=3840)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--alpha", type=float, default=0.15)
+    a = ap.parse_args()
+    H, W, F = a.H, a.W, a.frames
+    nt = (H // 8) * (W // 8)
+    ctx = api.Context(0)
+    rng = np.random.default_rng(1234)
+    host = rng.integers(0, 256, (F, H, W), dtype=np.uint8)
+    wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+    d_host = ctx.malloc(host.nbytes); ctx.h2d(d_host, host)
+    d_stego = ctx.malloc(host.nbytes)
+    d_wys = ctx.malloc(wys.nbytes); ctx.h2d(d_wys, wys)
+    d_U = ctx.malloc(nt * 64 * 4); d_V = ctx.malloc(nt * 64 * 4); d_S = ctx.malloc(nt * 8 * 4)
+    d_sc = ctx.malloc(F * nt * 8 * 4)
+    d_out = ctx.malloc(F * H * W * 4)
+    d_scores = ctx.malloc(F * 8)
+
+    def timed(name, fn, bytes_per_call):
+        fn(); ctx.sync()
+        ctx.event_record(0)
+        for _ in range(a.reps):
+            fn()
+        ctx.event_record(1)
+        ms = ctx.event_elapsed_ms(0, 1) / a.reps
+        print(f"{name:10s} {ms*1e3:10.1f} us/launch  {ms*1e3/F:9.1f} us/frame  "
+              f"{F/ms*1e3:10.0f} frames/s  {bytes_per_call/ms/1e9*1e3:8.1f} GB/s algorithmic", flush=True)
+        return ms
+
+    P = H * W
+    timed("svd_wm", lambda: ctx.svd_tiles_f32_dev(d_wys, d_U, d_S, d_V, 1, H, W, W, H * W), 12.5 * P / F * F)
+    timed("embed", lambda: ctx.embed_tiles_u8_dev(d_host, d_S, d_stego, d_sc, None, F, H, W, W, H * W, 0, a.alpha, 8), 3.0 * P * F)
+    timed("sigma", lambda: ctx.sigma_tiles_u8_dev(d_stego, d_sc, F, H, W, W, H * W), 1.5 * P * F)
+    ctx.embed_tiles_u8_dev(d_host, d_S, d_stego, d_sc, None, F, H, W, W, H * W, 0, a.alpha, 8)
+    timed("extract", lambda: ctx.extract_tiles_u8_dev(d_stego, d_sc, d_U, d_V, d_out, F, H, W, W, H * W, 0, a.alpha, 8), 10.5 * P * F)
+    timed("detect", lambda: ctx.detect_tiles_u8_dev(d_stego, d_sc, d_S, d_scores, F, H, W, W, H * W, 0, a.alpha), 2.0 * P * F)
+    ctx.check_status()
+    sc = np.zeros(F, np.float64); ctx.d2h(sc, d_scores)
+    print("detect scores", sc[:4])
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
