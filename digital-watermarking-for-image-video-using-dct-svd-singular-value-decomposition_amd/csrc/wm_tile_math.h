@@ -219,11 +219,191 @@ WM_HD int jacobi_svd8(float (&a)[8][8], float (&v)[8][8], float (&n2)[8], float 
   return more ? -sweep : sweep;   // negative: sweep bound hit before convergence
 }
 
+// ============================================================================
+// Packed (v_pk_*_f32) V-free formulation - the production embed/sigma path.
+//
+// Two identities remove ~45 % of the arithmetic of the literal chain
+// dct2 -> svd -> U diag(S') V^T -> idct2 without changing its result beyond
+// float32 rounding (parity is checked against the literal oracle):
+//  (1) the DCT is orthonormal:  svd(D X D^T) = (D Ux) S (D Vx)^T, so the
+//      singular values of the DCT plane ARE those of the pixel tile and
+//      idct2(Uc S' Vc^T) = Ux S' Vx^T: forward and inverse DCT cancel.
+//  (2) with S' = S + w (w_i = alpha*sw_i for i < K):
+//      Ux S' Vx^T = X + Ux diag(w_i / s_i) Ux^T X,  because Vx^T = S^-1 Ux^T X.
+//      One-sided Jacobi delivers B = X V = Ux S directly, so V is never formed.
+// Rounding noise of (2) is (w_i/s_i) * eps * |X|; tiles whose smallest singular
+// value is below SIGMA_RATIO_MIN * s_1 (flat / rank-deficient tiles) take the
+// literal DCT-domain path (embed_tile) instead.
+//
+// Register layout: rows are packed in pairs, a[rp][c] = (x[2rp][c], x[2rp+1][c]),
+// so a column rotation is the same packed op on 4 registers per column.
+// ============================================================================
+typedef float v2f __attribute__((vector_size(8)));
+
+WM_HD v2f splat2(float s) { v2f r = {s, s}; return r; }
+WM_HD v2f fma2(v2f a, v2f b, v2f c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_elementwise_fma(a, b, c);
+#else
+  v2f r = {fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+  return r;
+#endif
+}
+
+constexpr float SIGMA_RATIO_MIN2 = 1e-10f;   // (s_8 / s_1)^2 below this -> literal path
+
+// one Jacobi rotation of columns p,q (no V).  c0 = cos, s0 = sin*sign(g) from
+// two v_rsq_f32:  cos^2 = (1 + |tau|/h)/2,  sin = g / (h cos),  h^2 = tau^2+4g^2.
+WM_HD void jacobi_rot_pk(v2f (&a)[4][8], float (&n2)[8], const int p, const int q, bool& notconv) {
+  v2f gv = a[0][p] * a[0][q];
+#pragma unroll
+  for (int rp = 1; rp < 4; ++rp) gv = fma2(a[rp][p], a[rp][q], gv);
+  const float g = gv[0] + gv[1];
+  const float al = n2[p], be = n2[q];
+  notconv = notconv || (g * g > JAC_CONV2 * (al * be));
+  const float tau = be - al;
+  const float ta = fabsf(tau) + 1e-18f;          // keeps 0/0 out: g == 0 -> cos = 1 exactly
+  const float g2 = g + g;
+  const float ih = frsq(ffma(g2, g2, ta * ta));  // 1/h
+  const float x = ffma(0.5f * ta, ih, 0.5f);     // cos^2 in [0.5, 1]
+  const float rx = frsq(x);
+  const float c0 = x * rx;
+  const float s0 = (g * ih) * rx;
+  const bool sw = tau > 0.0f;                    // de Rijk: larger column ends in p
+  const float C = sw ? s0 : c0, Sn = sw ? c0 : s0;
+  const float w = fabsf((s0 * rx) * g);          // |t * g|: the larger norm grows by it
+  n2[p] = fmaxf(al, be) + w;
+  n2[q] = fminf(al, be) - w;
+  const v2f Cv = splat2(C), Sv = splat2(Sn);
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp) {
+    const v2f X = a[rp][p], Y = a[rp][q];
+    a[rp][p] = fma2(Cv, X, Sv * Y);
+    a[rp][q] = fma2(Cv, Y, -(Sv * X));
+  }
+}
+
+WM_HD void col_norms2_pk(const v2f (&a)[4][8], float (&n2)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    v2f s = a[0][c] * a[0][c];
+#pragma unroll
+    for (int rp = 1; rp < 4; ++rp) s = fma2(a[rp][c], a[rp][c], s);
+    n2[c] = s[0] + s[1];
+  }
+}
+
+// B = X V with orthogonal columns sorted by norm; n2 = |b_i|^2.  Returns the
+// sweep count (negative: bound hit).
+WM_HD int jacobi_cols_pk(v2f (&a)[4][8], float (&n2)[8]) {
+  int sweep = 0;
+  bool more = true;
+  while (more && sweep < JAC_MAX_SWEEPS) {
+    col_norms2_pk(a, n2);
+    bool notconv = false;
+#pragma unroll
+    for (int p = 0; p < 7; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 8; ++q) jacobi_rot_pk(a, n2, p, q, notconv);
+    ++sweep;
+    more = wave_any(notconv);
+  }
+  col_norms2_pk(a, n2);
+  return more ? -sweep : sweep;
+}
+
+// raw tile: 8 rows x (lo, hi) little-endian byte words, as loaded from memory
+struct RawTile { uint32_t lo[8], hi[8]; };
+
+WM_HD float raw_px(const RawTile& t, const int r, const int c) {
+  const uint32_t w = (c < 4) ? t.lo[r] : t.hi[r];
+  return (float)((w >> (8 * (c & 3))) & 0xffu);
+}
+WM_HD void raw_to_pk(const RawTile& t, v2f (&a)[4][8]) {
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v2f v = {raw_px(t, 2 * rp, c), raw_px(t, 2 * rp + 1, c)};
+      a[rp][c] = v;
+    }
+}
+WM_HD void raw_to_f32(const RawTile& t, float (&a)[8][8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[r][c] = raw_px(t, r, c);
+}
+
+// singular values of a raw uint8 tile (pixel domain == DCT domain, identity (1))
+WM_HD int sigma_tile_pk(const RawTile& t, float (&s)[8]) {
+  v2f a[4][8];
+  float n2[8];
+  raw_to_pk(t, a);
+  const int sweeps = jacobi_cols_pk(a, n2);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = fsqrt(n2[i]);
+  return sweeps;
+}
+
 // ---- uint8 quantisation: np.clip(x, 0, 255).astype(np.uint8) ----------------
 WM_HD uint32_t quant_u8(float x) {
   x = fminf(fmaxf(x, 0.0f), 255.0f);   // NaN -> 0 via fmaxf
   return (uint32_t)x;                  // truncation toward zero
 }
+
+// V-free embed of a raw tile.  `out` receives the quantised stego bytes, sc the
+// host singular values Sc; when YW is true the unclipped float stego is written
+// through `yw` (row stride `yw_stride` floats).  Returns sweeps; `deficient` is
+// set when the tile must take the literal path instead.
+template <bool YW>
+WM_HD int embed_tile_pk(const RawTile& t, const float (&sw)[8], const float (&alpha_k)[8],
+                        float (&sc)[8], RawTile& out, float* yw, const size_t yw_stride,
+                        bool& deficient) {
+  v2f a[4][8];
+  float n2[8];
+  raw_to_pk(t, a);
+  const int sweeps = jacobi_cols_pk(a, n2);
+  deficient = !(n2[7] > SIGMA_RATIO_MIN2 * n2[0]);
+  float e[8];                                        // alpha_i sw_i / s_i^3
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float rs = frsq(fmaxf(n2[i], 1e-30f));
+    sc[i] = n2[i] * rs;
+    e[i] = (alpha_k[i] * sw[i]) * (rs * rs * rs);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { out.lo[r] = 0u; out.hi[r] = 0u; }
+  // column c of  Y = X + B diag(e) (B^T X)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    v2f xc[4];
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp) { v2f v = {raw_px(t, 2 * rp, c), raw_px(t, 2 * rp + 1, c)}; xc[rp] = v; }
+    v2f acc[4] = {xc[0], xc[1], xc[2], xc[3]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v2f pv = a[0][i] * xc[0];
+#pragma unroll
+      for (int rp = 1; rp < 4; ++rp) pv = fma2(a[rp][i], xc[rp], pv);
+      const v2f pe = splat2((pv[0] + pv[1]) * e[i]);  // e_i * (b_i . x_c)
+#pragma unroll
+      for (int rp = 0; rp < 4; ++rp) acc[rp] = fma2(a[rp][i], pe, acc[rp]);
+    }
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = 2 * rp + h;
+        const float y = acc[rp][h];
+        if (YW) yw[(size_t)r * yw_stride + c] = y;
+        const uint32_t q = quant_u8(y) << (8 * (c & 3));
+        if (c < 4) out.lo[r] |= q; else out.hi[r] |= q;
+      }
+  }
+  return sweeps;
+}
+
 
 // ---- embed: tile (already float, pixel domain) -> stego tile (float) --------
 // sw[8]: the watermark tile's singular values; alpha_k[i] = alpha for i < K,

@@ -55,6 +55,8 @@ struct wm_ctx {
   size_t scratch_bytes = 0;
   void* partials = nullptr;       // grow-only detect partial sums
   size_t partials_bytes = 0;
+  void* fb_list = nullptr;        // grow-only list of waves for the embed fallback
+  size_t fb_bytes = 0;
   hipEvent_t ev[N_EVENTS] = {};
 };
 
@@ -124,6 +126,40 @@ __device__ __forceinline__ void store_tile_u8(uint8_t* __restrict__ p, const siz
   }
 }
 
+template <bool ALIGNED>
+__device__ __forceinline__ void load_raw(const uint8_t* __restrict__ p, const size_t stride,
+                                         wm::RawTile& t) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (ALIGNED) {
+      const uint2 w = *reinterpret_cast<const uint2*>(p + r * stride);
+      t.lo[r] = w.x; t.hi[r] = w.y;
+    } else {
+      const uint8_t* q = p + r * stride;
+      t.lo[r] = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+      t.hi[r] = q[4] | (q[5] << 8) | (q[6] << 16) | ((uint32_t)q[7] << 24);
+    }
+  }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void store_raw(uint8_t* __restrict__ p, const size_t stride,
+                                          const wm::RawTile& t) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (ALIGNED) {
+      *reinterpret_cast<uint2*>(p + r * stride) = make_uint2(t.lo[r], t.hi[r]);
+    } else {
+      uint8_t* q = p + r * stride;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        q[i] = (uint8_t)(t.lo[r] >> (8 * i));
+        q[4 + i] = (uint8_t)(t.hi[r] >> (8 * i));
+      }
+    }
+  }
+}
+
 template <bool VEC>
 __device__ __forceinline__ void load_row8_f32(const float* __restrict__ p, float (&row)[8]) {
   if (VEC) {
@@ -178,32 +214,72 @@ __device__ __forceinline__ bool tile_coords(const Geom& g, int& t, int& ty, int&
 // ---------------------------------------------------------------------------
 // K1  fused embed   (a1 a2 a3 a4 a5 a6 a7; sigma_c side output)
 // ---------------------------------------------------------------------------
-template <bool ALIGNED, bool VECF>
-__global__ __launch_bounds__(WAVE) void k_embed_tiles(
+// Fast path: packed, V-free, pixel-domain (wm_tile_math.h identities (1),(2)).
+// Waves that contain a flat / rank-deficient tile append their id to
+// `fb_list` (fb_count = status[1]) and are redone by k_embed_fallback.
+template <bool ALIGNED, bool YW>
+__global__ __launch_bounds__(WAVE, 4) void k_embed_tiles(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status) {
+    int* __restrict__ status, uint32_t* __restrict__ fb_list) {
   int t, ty, tx;
   if (!tile_coords(g, t, ty, tx)) return;
   const size_t plane = blockIdx.y;
   const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
 
-  float a[8][8], sw[8], sc[8], alpha_k[8];
-  load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
+  wm::RawTile raw, out;
+  float sw[8], sc[8], alpha_k[8];
+  load_raw<ALIGNED>(host + off, g.row_stride, raw);
   load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
 #pragma unroll
   for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
+  float* ywp = YW ? yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8 : nullptr;
 
-  const int sweeps = wm::embed_tile(a, sw, alpha_k, sc);
+  bool deficient;
+  const int sweeps = wm::embed_tile_pk<YW>(raw, sw, alpha_k, sc, out, ywp, (size_t)g.W, deficient);
+  const unsigned long long dmask = __builtin_amdgcn_ballot_w64(deficient);
+  if (dmask != 0ull) {
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
+        (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+      const int slot = atomicAdd(status + 1, 1);
+      fb_list[slot] = blockIdx.y * gridDim.x + blockIdx.x;
+    }
+  }
   if (sweeps < 0) atomicOr(status, 1);
-
   store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
-  store_tile_u8<ALIGNED>(stego + off, g.row_stride, a);
-  if (yw != nullptr) {
-    float* o = yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
+  store_raw<ALIGNED>(stego + off, g.row_stride, out);
+}
+
+// Literal chain (dct2 -> svd with V -> U diag(S') V^T -> idct2) for the waves
+// listed by the fast kernel.  Persistent-style: a fixed grid strides the list.
+template <bool ALIGNED, bool YW>
+__global__ __launch_bounds__(WAVE, 2) void k_embed_fallback(
+    const uint8_t* host, const float* __restrict__ sigma_w,
+    uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
+    const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
+    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const unsigned waves_per_plane) {
+  const int count = status[1];
+  for (int it = blockIdx.x; it < count; it += gridDim.x) {
+    const unsigned wid = fb_list[it];
+    const size_t plane = wid / waves_per_plane;
+    const int t = (int)(wid % waves_per_plane) * WAVE + threadIdx.x;
+    if (t >= g.n_tiles) continue;
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
+    const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
+    float a[8][8], sw[8], sc[8], alpha_k[8];
+    load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
+    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
+    for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
+    if (wm::embed_tile(a, sw, alpha_k, sc) < 0) atomicOr(status, 1);
+    store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
+    store_tile_u8<ALIGNED>(stego + off, g.row_stride, a);
+    if (YW) {
+      float* o = yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) store_row8_f32<false>(o + (size_t)r * g.W, a[r]);
+    }
   }
 }
 
@@ -231,16 +307,17 @@ __global__ void k_copy_border(const uint8_t* host, uint8_t* stego,
 // K2  sigma only
 // ---------------------------------------------------------------------------
 template <bool ALIGNED>
-__global__ __launch_bounds__(WAVE) void k_sigma_tiles(const uint8_t* __restrict__ planes,
+__global__ __launch_bounds__(WAVE, 4) void k_sigma_tiles(const uint8_t* __restrict__ planes,
                                                      float* __restrict__ sigma, const Geom g,
                                                      int* __restrict__ status) {
   int t, ty, tx;
   if (!tile_coords(g, t, ty, tx)) return;
   const size_t plane = blockIdx.y;
-  float a[8][8], s[8];
-  load_tile_u8<ALIGNED>(planes + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
-                        g.row_stride, a);
-  if (wm::sigma_tile(a, s) < 0) atomicOr(status, 1);
+  wm::RawTile raw;
+  float s[8];
+  load_raw<ALIGNED>(planes + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
+                    g.row_stride, raw);
+  if (wm::sigma_tile_pk(raw, s) < 0) atomicOr(status, 1);
   store_row8_f32<true>(sigma + (plane * g.n_tiles + t) * 8, s);
 }
 
@@ -248,7 +325,7 @@ __global__ __launch_bounds__(WAVE) void k_sigma_tiles(const uint8_t* __restrict_
 // K3  full SVD of float tiles (watermark side)
 // ---------------------------------------------------------------------------
 template <bool VECF>
-__global__ __launch_bounds__(WAVE) void k_svd_tiles(const float* __restrict__ planes,
+__global__ __launch_bounds__(WAVE, 2) void k_svd_tiles(const float* __restrict__ planes,
                                                    float* __restrict__ U, float* __restrict__ S,
                                                    float* __restrict__ Vt, const Geom g,
                                                    int* __restrict__ status) {
@@ -270,7 +347,7 @@ __global__ __launch_bounds__(WAVE) void k_svd_tiles(const float* __restrict__ pl
 // K2+K4  fused extract
 // ---------------------------------------------------------------------------
 template <bool ALIGNED, bool VECF>
-__global__ __launch_bounds__(WAVE) void k_extract_tiles(
+__global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
     const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
     const float* __restrict__ Uw, const float* __restrict__ Vwt, float* __restrict__ out,
     const Geom g, const size_t uv_plane_stride, const float inv_alpha, const int K,
@@ -278,10 +355,11 @@ __global__ __launch_bounds__(WAVE) void k_extract_tiles(
   int t, ty, tx;
   if (!tile_coords(g, t, ty, tx)) return;
   const size_t plane = blockIdx.y;
+  wm::RawTile raw;
   float a[8][8], s[8], sc[8], keep[8];
-  load_tile_u8<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
-                        g.row_stride, a);
-  if (wm::sigma_tile(a, s) < 0) atomicOr(status, 1);
+  load_raw<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
+                    g.row_stride, raw);
+  if (wm::sigma_tile_pk(raw, s) < 0) atomicOr(status, 1);
   load_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
 #pragma unroll
   for (int i = 0; i < 8; ++i) keep[i] = (i < K) ? 1.0f : 0.0f;
@@ -299,7 +377,7 @@ __global__ __launch_bounds__(WAVE) void k_extract_tiles(
 // K4  reconstruct only:  Uw diag(sw_hat) Vwt -> idct
 // ---------------------------------------------------------------------------
 template <bool VECF>
-__global__ __launch_bounds__(WAVE) void k_reconstruct_tiles(
+__global__ __launch_bounds__(WAVE, 3) void k_reconstruct_tiles(
     const float* __restrict__ Uw, const float* __restrict__ sw_hat,
     const float* __restrict__ Vwt, float* __restrict__ out, const Geom g) {
   int t, ty, tx;
@@ -328,7 +406,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(WAVE) void k_detect_tiles(
+__global__ __launch_bounds__(WAVE, 4) void k_detect_tiles(
     const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
     const float* __restrict__ sigma_w, double* __restrict__ partials, const Geom g,
     const size_t sw_plane_stride, const float inv_alpha, int* __restrict__ status) {
@@ -337,10 +415,11 @@ __global__ __launch_bounds__(WAVE) void k_detect_tiles(
   double acc[N_SUMS] = {0, 0, 0, 0, 0};
   if (t < g.n_tiles) {
     const int ty = t / g.nbx, tx = t - ty * g.nbx;
-    float a[8][8], s[8], sc[8], sw[8];
-    load_tile_u8<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
-                          g.row_stride, a);
-    if (wm::sigma_tile(a, s) < 0) atomicOr(status, 1);
+    wm::RawTile raw;
+    float s[8], sc[8], sw[8];
+    load_raw<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
+                      g.row_stride, raw);
+    if (wm::sigma_tile_pk(raw, s) < 0) atomicOr(status, 1);
     load_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
     load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
 #pragma unroll
@@ -484,8 +563,8 @@ int wm_create(int device, void* stream, wm_ctx** ctx_out) {
     if (e != hipSuccess) { delete ctx; return set_err(WM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ctx->owns_stream = true;
   }
-  hipError_t e = hipMalloc((void**)&ctx->d_status, sizeof(int));
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream);
+  hipError_t e = hipMalloc((void**)&ctx->d_status, 2 * sizeof(int));   // [0] status, [1] fallback count
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 2 * sizeof(int), ctx->stream);
   for (int i = 0; i < N_EVENTS && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
   if (e != hipSuccess) { wm_destroy(ctx); return set_err(WM_ERR_HIP, "context setup: %s", hipGetErrorString(e)); }
   *ctx_out = ctx;
@@ -500,6 +579,7 @@ int wm_destroy(wm_ctx* ctx) {
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->partials) (void)hipFree(ctx->partials);
+  if (ctx->fb_list) (void)hipFree(ctx->fb_list);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return WM_OK;
@@ -589,14 +669,23 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
     if ((((uintptr_t)sigma_w | (uintptr_t)sigma_c) & 15u) || (sigma_w_plane_stride & 3u))
       return set_err(WM_ERR_BADARG, "sigma arrays must be 16-byte aligned");
     const bool al = u8_aligned(host, stego, row_stride, plane_stride);
-    const bool vf = yw ? f32_vec_ok(yw, (size_t)W, g.HW) : true;
     const dim3 grid = tile_grid(g, n_planes), block(WAVE);
-#define WM_LAUNCH_EMBED(A, V)                                                                  \
-  hipLaunchKernelGGL((k_embed_tiles<A, V>), grid, block, 0, ctx->stream, host, sigma_w, stego, \
-                     sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status)
-    if (al && vf) WM_LAUNCH_EMBED(true, true);
+    const size_t n_waves = (size_t)grid.x * grid.y;
+    WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, n_waves * sizeof(uint32_t), "fallback list"));
+    WM_HIP(hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int), ctx->stream));
+    uint32_t* fb = (uint32_t*)ctx->fb_list;
+    const dim3 fgrid((unsigned)(n_waves < 2048 ? n_waves : 2048));
+#define WM_LAUNCH_EMBED(A, Y)                                                                      \
+  do {                                                                                             \
+    hipLaunchKernelGGL((k_embed_tiles<A, Y>), grid, block, 0, ctx->stream, host, sigma_w, stego,   \
+                       sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb);         \
+    hipLaunchKernelGGL((k_embed_fallback<A, Y>), fgrid, block, 0, ctx->stream, host, sigma_w,      \
+                       stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb,   \
+                       grid.x);                                                                    \
+  } while (0)
+    if (al && yw) WM_LAUNCH_EMBED(true, true);
     else if (al) WM_LAUNCH_EMBED(true, false);
-    else if (vf) WM_LAUNCH_EMBED(false, true);
+    else if (yw) WM_LAUNCH_EMBED(false, true);
     else WM_LAUNCH_EMBED(false, false);
 #undef WM_LAUNCH_EMBED
     WM_HIP(hipGetLastError());

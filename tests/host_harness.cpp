@@ -103,6 +103,74 @@ int hh_extract_tiles_u8(const uint8_t* stego, const float* sigma_c, const float*
   return 0;
 }
 
+
+static inline void load_raw(const uint8_t* p, int stride, RawTile& t) {
+  for (int r = 0; r < 8; ++r) {
+    const uint8_t* q = p + (size_t)r * stride;
+    t.lo[r] = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+    t.hi[r] = q[4] | (q[5] << 8) | (q[6] << 16) | ((uint32_t)q[7] << 24);
+  }
+}
+
+// production formulation (packed, V-free, pixel domain) with the literal fallback,
+// mirroring k_embed_tiles
+int hh_embed_tiles_u8_pk(const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,
+                         float* yw, int H, int W, int row_stride, float alpha, int K, int* max_sweeps,
+                         int* n_fallback) {
+  const int nby = H / 8, nbx = W / 8;
+  float alpha_k[8];
+  for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
+  int ms = 0, nf = 0;
+  for (int r = 0; r < H; ++r) memcpy(stego + (size_t)r * row_stride, host + (size_t)r * row_stride, W);
+  if (yw)
+    for (int r = 0; r < H; ++r)
+      for (int c = 0; c < W; ++c) yw[(size_t)r * W + c] = (float)host[(size_t)r * row_stride + c];
+  for (int ty = 0; ty < nby; ++ty)
+    for (int tx = 0; tx < nbx; ++tx) {
+      const size_t t = (size_t)ty * nbx + tx;
+      RawTile raw, out;
+      float sw[8], sc[8], y[8][8];
+      load_raw(host + (size_t)ty * 8 * row_stride + tx * 8, row_stride, raw);
+      for (int i = 0; i < 8; ++i) sw[i] = sigma_w[t * 8 + i];
+      bool deficient = false;
+      int s = embed_tile_pk<true>(raw, sw, alpha_k, sc, out, &y[0][0], 8, deficient);
+      if (deficient) {
+        ++nf;
+        raw_to_f32(raw, y);
+        s = embed_tile(y, sw, alpha_k, sc);
+        for (int r = 0; r < 8; ++r) {
+          out.lo[r] = quant_u8(y[r][0]) | (quant_u8(y[r][1]) << 8) | (quant_u8(y[r][2]) << 16) | (quant_u8(y[r][3]) << 24);
+          out.hi[r] = quant_u8(y[r][4]) | (quant_u8(y[r][5]) << 8) | (quant_u8(y[r][6]) << 16) | (quant_u8(y[r][7]) << 24);
+        }
+      }
+      if (s > ms) ms = s;
+      for (int i = 0; i < 8; ++i) sigma_c[t * 8 + i] = sc[i];
+      for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) {
+          const uint32_t w = (c < 4) ? out.lo[r] : out.hi[r];
+          stego[(size_t)(ty * 8 + r) * row_stride + tx * 8 + c] = (uint8_t)(w >> (8 * (c & 3)));
+          if (yw) yw[(size_t)(ty * 8 + r) * W + tx * 8 + c] = y[r][c];
+        }
+    }
+  if (max_sweeps) *max_sweeps = ms;
+  if (n_fallback) *n_fallback = nf;
+  return 0;
+}
+
+int hh_sigma_tiles_u8_pk(const uint8_t* plane, float* sigma, int H, int W, int row_stride, int* sweep_hist) {
+  const int nby = H / 8, nbx = W / 8;
+  for (int ty = 0; ty < nby; ++ty)
+    for (int tx = 0; tx < nbx; ++tx) {
+      RawTile raw;
+      float s[8];
+      load_raw(plane + (size_t)ty * 8 * row_stride + tx * 8, row_stride, raw);
+      int sw = sigma_tile_pk(raw, s);
+      if (sweep_hist) { if (sw < 0) sw = 15; sweep_hist[sw > 15 ? 15 : sw]++; }
+      for (int i = 0; i < 8; ++i) sigma[((size_t)ty * nbx + tx) * 8 + i] = s[i];
+    }
+  return 0;
+}
+
 void hh_dct8x8(float* tile, int inverse) {
   float a[8][8];
   memcpy(a, tile, sizeof(a));

@@ -35,7 +35,7 @@ def test_embed_parity(gpu_ctx, H, W):
     d = np.abs(stego.astype(np.int32) - ref["stego"].astype(np.int32))
     assert d.max() <= 1
     assert np.mean(d != 0) < 2e-3          # truncation flips only where Yw sits on an integer
-    assert np.abs(yw - ref["Yw"]).max() < 5e-3
+    assert np.abs(yw - ref["Yw"]).max() < 3e-2   # (w_i/s_i) * eps * |X| for the smallest s_i
     assert abs(o.psnr(host, stego) - o.psnr(host, ref["stego"])) < 1e-3
 
 
@@ -59,7 +59,7 @@ def test_svd_tiles_parity(gpu_ctx):
 def test_sigma_extract_detect_parity(gpu_ctx, K):
     H, W, alpha = 512, 512, 0.15
     host, wys = _inputs(H, W)
-    ref = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, tile=8, k_floor=K, kfrac=0.0)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, kfrac=0.0, tile=8, k_floor=K)
     st = ref["stego"]
     s = gpu_ctx.sigma_tiles(st)
     assert _rel_sigma(s, o.stego_sigma(st.astype(np.float32), 8)) < SIGMA_RTOL
