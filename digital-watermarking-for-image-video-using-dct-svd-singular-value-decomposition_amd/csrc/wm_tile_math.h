@@ -272,7 +272,7 @@ WM_HD void jacobi_rot_pk(v2f (&a)[4][8], float (&n2)[8], const int p, const int 
   const bool sw = tau > 0.0f;                    // de Rijk: larger column ends in p
   const float C = sw ? s0 : c0, Sn = sw ? c0 : s0;
   const float w = fabsf((s0 * rx) * g);          // |t * g|: the larger norm grows by it
-  n2[p] = fmaxf(al, be) + w;
+  n2[p] = fmaxf(al, be) + w;                     // (cancellation-free, unlike (al+be+-h)/2)
   n2[q] = fminf(al, be) - w;
   const v2f Cv = splat2(C), Sv = splat2(Sn);
 #pragma unroll
@@ -372,34 +372,50 @@ WM_HD int embed_tile_pk(const RawTile& t, const float (&sw)[8], const float (&al
     sc[i] = n2[i] * rs;
     e[i] = (alpha_k[i] * sw[i]) * (rs * rs * rs);
   }
+  // Y = X + B G with G = diag(e) (B^T X), done in two column halves (columns
+  // 0-3 -> the lo words, 4-7 -> the hi words) so only half of G is live.
+  // Columns are packed in pairs, g[i][cp] = (G[i][2cp], G[i][2cp+1]); b_i[r] is
+  // one half of a[r>>1][i], broadcast by the packed FMA's op_sel.
 #pragma unroll
-  for (int r = 0; r < 8; ++r) { out.lo[r] = 0u; out.hi[r] = 0u; }
-  // column c of  Y = X + B diag(e) (B^T X)
+  for (int h = 0; h < 2; ++h) {
+    v2f g[8][2];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    v2f xc[4];
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t w = h ? t.hi[r] : t.lo[r];
+      const v2f x0 = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
+      const v2f x1 = {(float)((w >> 16) & 0xffu), (float)(w >> 24)};
 #pragma unroll
-    for (int rp = 0; rp < 4; ++rp) { v2f v = {raw_px(t, 2 * rp, c), raw_px(t, 2 * rp + 1, c)}; xc[rp] = v; }
-    v2f acc[4] = {xc[0], xc[1], xc[2], xc[3]};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v2f pv = a[0][i] * xc[0];
-#pragma unroll
-      for (int rp = 1; rp < 4; ++rp) pv = fma2(a[rp][i], xc[rp], pv);
-      const v2f pe = splat2((pv[0] + pv[1]) * e[i]);  // e_i * (b_i . x_c)
-#pragma unroll
-      for (int rp = 0; rp < 4; ++rp) acc[rp] = fma2(a[rp][i], pe, acc[rp]);
+      for (int i = 0; i < 8; ++i) {
+        const v2f b = splat2(a[r >> 1][i][r & 1]);
+        g[i][0] = (r == 0) ? b * x0 : fma2(b, x0, g[i][0]);
+        g[i][1] = (r == 0) ? b * x1 : fma2(b, x1, g[i][1]);
+      }
     }
 #pragma unroll
-    for (int rp = 0; rp < 4; ++rp)
+    for (int i = 0; i < 8; ++i) {
+      const v2f ev = splat2(e[i]);
+      g[i][0] = g[i][0] * ev;
+      g[i][1] = g[i][1] * ev;
+    }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = 2 * rp + h;
-        const float y = acc[rp][h];
-        if (YW) yw[(size_t)r * yw_stride + c] = y;
-        const uint32_t q = quant_u8(y) << (8 * (c & 3));
-        if (c < 4) out.lo[r] |= q; else out.hi[r] |= q;
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t w = h ? t.hi[r] : t.lo[r];
+      v2f y0 = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
+      v2f y1 = {(float)((w >> 16) & 0xffu), (float)(w >> 24)};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const v2f b = splat2(a[r >> 1][i][r & 1]);
+        y0 = fma2(b, g[i][0], y0);
+        y1 = fma2(b, g[i][1], y1);
       }
+      if (YW) {
+        float* o = yw + (size_t)r * yw_stride + 4 * h;
+        o[0] = y0[0]; o[1] = y0[1]; o[2] = y1[0]; o[3] = y1[1];
+      }
+      const uint32_t q = quant_u8(y0[0]) | (quant_u8(y0[1]) << 8) | (quant_u8(y1[0]) << 16) |
+                         (quant_u8(y1[1]) << 24);
+      if (h) out.hi[r] = q; else out.lo[r] = q;
+    }
   }
   return sweeps;
 }

@@ -218,7 +218,7 @@ __device__ __forceinline__ bool tile_coords(const Geom& g, int& t, int& ty, int&
 // Waves that contain a flat / rank-deficient tile append their id to
 // `fb_list` (fb_count = status[1]) and are redone by k_embed_fallback.
 template <bool ALIGNED, bool YW>
-__global__ __launch_bounds__(WAVE, 4) void k_embed_tiles(
+__global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
