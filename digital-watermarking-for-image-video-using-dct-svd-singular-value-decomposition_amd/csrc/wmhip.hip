@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int N_EVENTS = 16;
+constexpr int N_EVENTS = 64;
 constexpr int N_SUMS = 5;          // detect: sum a, b, ab, aa, bb
 
 thread_local char g_err[512] = "";

@@ -1,0 +1,225 @@
+"""Drop-in for the reference's ``embed / extract / detect`` surface
+(app_dct_svd_single.py:112-318 - the authoritative "SECURE CORE"; imported by
+app_dct_svd_pyside6.py:8 as ``from dct_svd_core_secure import embed, extract,
+detect``), with the numeric hot path on MI355X HIP kernels.
+
+Same positional/keyword arguments, return values, side effects (``_stego.png``
+/ ``_wm.png`` renaming, ``.npz`` meta with the same keys) and exception types
+as the reference.  Keyword-only extras, all with reference-preserving
+defaults where the reference has a behaviour:
+
+  tile     8 (default): the north_star's block formulation - the reference's
+           per-matrix arithmetic applied to every 8x8 tile.
+           Its meta carries ``tile=8`` and is not readable by the reference's
+           own full-frame extract.  ``tile=None`` (reference full-frame
+           semantics) has no GPU kernel yet and raises NotImplementedError -
+           there is deliberately no CPU fallback.
+  k_floor  the literal 8 of ``K = max(8, int(kfrac*L))`` (single:174); at
+           tile=8 the formula is 8 for every kfrac, so a mid-band sweep sets
+           k_floor < 8.
+  nonce    inject the 8-byte nonce (reference: ``os.urandom(8)``, single:119).
+  device   HIP device index.
+
+``embed_watermark`` / ``extract_watermark`` are aliases (the names
+BASELINE.json's north_star uses).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import hostapi
+from . import hostglue as hg
+
+K_FRAC_DEFAULT = hg.K_FRAC_DEFAULT
+TILE = 8
+
+_contexts = {}
+
+
+def _ctx(device: int = 0) -> hostapi.Context:
+    c = _contexts.get(device)
+    if c is None:
+        c = _contexts[device] = hostapi.Context(device)
+    return c
+
+
+def _k_of(L: int, kfrac: float, k_floor: int) -> int:
+    return min(L, max(int(k_floor), int(kfrac * L)))     # single:174 (capped at L = 8)
+
+
+def _need_tile(tile):
+    if tile is None:
+        raise NotImplementedError(
+            "tile=None (full-frame reference semantics) has no GPU kernel yet; "
+            "use tile=8.  There is no CPU fallback.")
+    if int(tile) != TILE:
+        raise ValueError("tile must be 8")
+
+
+# ---------------------------------------------------------------------------
+# array level (decoded images in, arrays out) - what the file level wraps
+# ---------------------------------------------------------------------------
+def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
+                 alpha: float = 0.1, color: bool = False, kfrac: float = K_FRAC_DEFAULT,
+                 tile: Optional[int] = TILE, k_floor: int = 8, device: int = 0) -> dict:
+    """cover, wm: BGR uint8.  Returns dict(stego BGR uint8, meta dict, psnr, ssim)."""
+    if not password:
+        raise ValueError("Vui lòng nhập mật khẩu để nhúng.")              # single:115-116
+    _need_tile(tile)
+    ctx = _ctx(device)
+    H, W = cover.shape[:2]
+    wm = hg.resize_area(wm, W, H)                                          # single:118
+    key = hg.derive_key(password, nonce)                                   # single:119
+    idx = hg.permutation_index(H, W, key)
+    K = _k_of(TILE, kfrac, k_floor)
+    common = dict(payload_type="image", shape=np.array((H, W)), alpha=float(alpha),
+                  kfrac=float(kfrac), nonce=np.frombuffer(nonce, dtype=np.uint8),
+                  tile=np.int32(TILE), k_floor=np.int32(k_floor))
+    if color:
+        hosts = np.ascontiguousarray(np.moveaxis(cover, -1, 0))            # b, g, r planes  single:122
+        wms = np.stack([hg.permute(wm[..., ch].astype(np.float32), idx) for ch in range(3)])  # single:123-126
+        U, S, Vt = ctx.svd_tiles(wms)                                      # single:131-134
+        stego_p, Sc, _ = ctx.embed_tiles(hosts, S, alpha, K)               # single:127-147
+        stego = np.ascontiguousarray(np.moveaxis(stego_p, 0, -1))
+        meta = dict(mode="color", **common)
+        for ch, n in enumerate("bgr"):
+            meta["S" + n] = Sc[ch]; meta["UW" + n] = U[ch]
+            meta["VW" + n + "t"] = Vt[ch]; meta["SW" + n] = S[ch]
+        digest = hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"],
+                                      meta["UWb"], meta["UWg"], meta["UWr"],
+                                      meta["VWbt"], meta["VWgt"], meta["VWrt"]])   # single:152-156
+        meta["digest"] = np.frombuffer(digest, dtype=np.uint8)
+        return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego), ssim=hg.ssim(cover, stego))  # single:167
+    ycc = hg.bgr_to_ycrcb(cover)                                           # single:169
+    Y = np.ascontiguousarray(ycc[..., 0])
+    wy_s = hg.permute(hg.bgr_to_gray(wm).astype(np.float32), idx)          # single:170-171
+    Uw, Sw, Vwt = ctx.svd_tiles(wy_s)                                      # single:173
+    stegoY, Sc, Yw = ctx.embed_tiles(Y, Sw, alpha, K, want_yw=True)        # single:172-177
+    out = ycc.copy(); out[..., 0] = stegoY                                 # single:27-29
+    stego = hg.ycrcb_to_bgr(out)                                           # single:30
+    digest = hg.hmac_digest(key, [Sc, Uw, Vwt])                            # single:182
+    meta = dict(mode="gray", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw, **common,
+                digest=np.frombuffer(digest, dtype=np.uint8))              # single:183-189
+    return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego),
+                ssim=hg.ssim(hg.bgr_to_gray(cover), Yw))                   # single:190
+
+
+def _meta_tile(meta) -> Optional[int]:
+    return int(meta["tile"]) if "tile" in meta else None
+
+
+def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = True,
+                   device: int = 0) -> np.ndarray:
+    """Watermark estimate (uint8 [H,W] gray / [H,W,3] colour) before the
+    reference's cosmetic denoise/enhance step (single:223-227,275-277)."""
+    if not password:
+        raise ValueError("Vui lòng nhập mật khẩu để giải trích.")          # single:193-194
+    mode = str(meta["mode"]); alpha = float(meta["alpha"])                 # single:196
+    H, W = map(int, meta["shape"])
+    nonce = bytes(bytearray(np.asarray(meta["nonce"]).astype(np.uint8).tolist()))
+    digest = bytes(bytearray(np.asarray(meta["digest"]).astype(np.uint8).tolist()))
+    key = hg.derive_key(password, nonce)                                   # single:200
+    kfrac = float(meta["kfrac"]) if "kfrac" in meta else K_FRAC_DEFAULT    # single:211
+    k_floor = int(meta["k_floor"]) if "k_floor" in meta else 8
+    if mode == "gray":
+        parts = [meta["Sc"], meta["Uw"], meta["Vwt"]]
+    else:
+        parts = [meta["S" + n] for n in "bgr"] + [meta["UW" + n] for n in "bgr"] \
+            + [meta["VW" + n + "t"] for n in "bgr"]
+    if not hg.digests_equal(hg.hmac_digest(key, parts), digest):
+        raise ValueError("Sai mật khẩu hoặc meta không khớp.")             # single:208-209,246-247
+    _need_tile(_meta_tile(meta))
+    ctx = _ctx(device)
+    K = _k_of(TILE, kfrac, k_floor)
+    idx = hg.permutation_index(H, W, key)                                  # single:219,265
+    if mode == "gray":
+        Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])           # single:204
+        wy_s = ctx.extract_tiles(Y, meta["Sc"], meta["Uw"], meta["Vwt"], alpha, K)   # single:205-218
+        wy = hg.unpermute(wy_s, idx)                                       # single:220
+        if normalize:
+            wy = hg.normalize_minmax(wy)                                   # single:221
+        return np.clip(wy, 0, 255).astype(np.uint8)                        # single:222
+    planes = np.ascontiguousarray(np.moveaxis(stego, -1, 0))               # single:232
+    Sc = np.stack([meta["S" + n] for n in "bgr"])
+    U = np.stack([meta["UW" + n] for n in "bgr"])
+    Vt = np.stack([meta["VW" + n + "t"] for n in "bgr"])
+    ws = ctx.extract_tiles(planes, Sc, U, Vt, alpha, K)                    # single:233-264
+    outs = []
+    for ch in range(3):
+        w = hg.unpermute(ws[ch], idx)                                      # single:266-267
+        if normalize:
+            w = hg.normalize_minmax(w)                                     # single:269-271
+        outs.append(np.clip(w, 0, 255).astype(np.uint8))                   # single:272-274
+    return np.stack(outs, axis=-1)
+
+
+def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0):
+    mode = str(meta["mode"]); alpha = float(meta["alpha"])                 # single:293
+    _need_tile(_meta_tile(meta))
+    ctx = _ctx(device)
+    if mode == "gray":
+        Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])           # single:296
+        score = float(ctx.detect_tiles(Y, meta["Sc"], meta["Sw"], alpha)[0])   # single:297-301
+        return bool(score >= thresh), score                                # single:302
+    planes = np.ascontiguousarray(np.moveaxis(stego, -1, 0))               # single:303
+    Sc = np.stack([meta["S" + n] for n in "bgr"])
+    Sw = np.stack([meta["SW" + n] for n in "bgr"])
+    nc = ctx.detect_tiles(planes, Sc, Sw, alpha)                           # single:304-316
+    score = float((nc[0] + nc[1] + nc[2]) / 3.0)                           # single:317
+    return bool(score >= thresh), score                                    # single:318
+
+
+# ---------------------------------------------------------------------------
+# file level: the reference's public functions
+# ---------------------------------------------------------------------------
+def embed(cover_path: str, wm_source: str, out_path: str, meta_path: str,
+          alpha: float = 0.1, color: bool = False, password: Optional[str] = None,
+          kfrac: float = K_FRAC_DEFAULT, *, tile: Optional[int] = TILE, k_floor: int = 8,
+          nonce: Optional[bytes] = None, device: int = 0):
+    """single:112-190.  Returns (out_path, meta_path, psnr, ssim)."""
+    if not password:
+        raise ValueError("Vui lòng nhập mật khẩu để nhúng.")
+    cover = hg.read_image_bgr(cover_path)                                  # single:117
+    wm = hg.read_image_bgr(wm_source)                                      # single:118
+    if nonce is None:
+        nonce = os.urandom(8)                                              # single:119
+    r = embed_arrays(cover, wm, password, nonce, alpha, color, kfrac, tile, k_floor, device)
+    if not out_path.lower().endswith(".png"):
+        out_path = os.path.splitext(out_path)[0] + "_stego.png"            # single:148-149,178-179
+    if not hg.write_png(out_path, r["stego"], 0):                          # single:150,180
+        raise IOError("Ghi stego thất bại.")
+    np.savez_compressed(meta_path, **r["meta"])                            # single:157-166,183-189
+    return out_path, meta_path, r["psnr"], r["ssim"]
+
+
+def extract(stego_path: str, meta_path: str, out_path: str, password: str,
+            normalize: bool = True, *, enhance: bool = False, device: int = 0) -> str:
+    """single:192-282.  ``enhance=True`` applies the unsharp half of the
+    reference's cosmetic post-processing (CLAHE / NL-means are OpenCV-only and
+    wrapped in try/except there); default writes the extracted plane as is."""
+    if not password:
+        raise ValueError("Vui lòng nhập mật khẩu để giải trích.")
+    data = np.load(meta_path, allow_pickle=False)                          # single:195
+    st = hg.read_image_bgr(stego_path)                                     # single:201
+    wm = extract_arrays(st, data, password, normalize, device)
+    if enhance:
+        wm = hg.unsharp(wm, 0.25 if wm.ndim == 2 else 0.15)               # single:95,109
+    if not out_path.lower().endswith(".png"):
+        out_path = os.path.splitext(out_path)[0] + "_wm.png"               # single:225-226,278-279
+    if not hg.write_png(out_path, wm, 1):
+        raise IOError("Ghi watermark thất bại.")                           # single:229,281
+    return out_path
+
+
+def detect(stego_path: str, meta_path: str, thresh: float = 0.6, *, device: int = 0):
+    """single:291-318.  Returns (bool, score)."""
+    data = np.load(meta_path, allow_pickle=False)                          # single:292
+    st = hg.read_image_bgr(stego_path)                                     # single:294
+    return detect_arrays(st, data, thresh, device)
+
+
+embed_watermark = embed
+extract_watermark = extract

@@ -1,0 +1,201 @@
+"""Host-side glue of the drop-in (NumPy / SciPy / Pillow): the parts of the
+reference that BASELINE.json's north_star keeps on the host - image I/O,
+colour conversion, watermark resize, password -> key -> permutation, HMAC,
+PSNR / SSIM.  Citations are into /root/reference/app_dct_svd_single.py
+("single").  OpenCV is not available in this image, so every ``cv2.*`` call
+is restated from OpenCV's documented formulas.  No numerics of the hot path
+(DCT / SVD / reconstruction) live here - those are HIP kernels behind
+include/wmhip.h.
+"""
+from __future__ import annotations
+
+import hashlib
+import hmac as _hmac
+
+import numpy as np
+import scipy.ndimage
+from PIL import Image
+
+K_FRAC_DEFAULT = 0.6  # single:13
+
+
+# ---- image I/O  (single:15-19, 150, 180, 228, 280) --------------------------
+def read_image_bgr(path: str) -> np.ndarray:
+    """``cv2.imread(path, cv2.IMREAD_COLOR)``: always 3-channel BGR uint8."""
+    try:
+        with Image.open(path) as im:
+            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    except Exception:
+        raise ValueError(f"Không mở được ảnh: {path}")          # single:17-18
+    return np.ascontiguousarray(rgb[..., ::-1])
+
+
+def write_png(path: str, img: np.ndarray, compression: int = 0) -> bool:
+    """``cv2.imwrite(path, img, [IMWRITE_PNG_COMPRESSION, c])`` for BGR or gray uint8."""
+    try:
+        if img.ndim == 2:
+            Image.fromarray(img, mode="L").save(path, format="PNG", compress_level=compression)
+        else:
+            Image.fromarray(np.ascontiguousarray(img[..., ::-1]), mode="RGB").save(
+                path, format="PNG", compress_level=compression)
+        return True
+    except Exception:
+        return False
+
+
+# ---- colour conversion (OpenCV 8-bit fixed point) ---------------------------
+def bgr_to_gray(bgr: np.ndarray) -> np.ndarray:
+    """cv2.COLOR_BGR2GRAY: (B*3735 + G*19235 + R*9798 + 2^14) >> 15."""
+    b = bgr[..., 0].astype(np.int32); g = bgr[..., 1].astype(np.int32); r = bgr[..., 2].astype(np.int32)
+    return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+def bgr_to_ycrcb(bgr: np.ndarray) -> np.ndarray:
+    """cv2.COLOR_BGR2YCrCb (single:22), 14-bit coefficients 4899/9617/1868, 11682, 9241."""
+    b = bgr[..., 0].astype(np.int32); g = bgr[..., 1].astype(np.int32); r = bgr[..., 2].astype(np.int32)
+    y = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14
+    cr = ((r - y) * 11682 + (128 << 14) + 8192) >> 14
+    cb = ((b - y) * 9241 + (128 << 14) + 8192) >> 14
+    out = np.stack([y, cr, cb], axis=-1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def ycrcb_to_bgr(ycc: np.ndarray) -> np.ndarray:
+    """cv2.COLOR_YCrCb2BGR (single:30), coefficients 22987, -11698, -5636, 29049."""
+    y = ycc[..., 0].astype(np.int32)
+    cr = ycc[..., 1].astype(np.int32) - 128
+    cb = ycc[..., 2].astype(np.int32) - 128
+    b = y + ((cb * 29049 + 8192) >> 14)
+    g = y + ((cb * -5636 + cr * -11698 + 8192) >> 14)
+    r = y + ((cr * 22987 + 8192) >> 14)
+    return np.clip(np.stack([b, g, r], axis=-1), 0, 255).astype(np.uint8)
+
+
+# ---- watermark resize (single:118) -------------------------------------------
+def _area_matrix(n_src: int, n_dst: int) -> np.ndarray:
+    M = np.zeros((n_dst, n_src), np.float64)
+    scale = n_src / n_dst
+    if scale >= 1.0:           # shrink: fractional box coverage
+        for d in range(n_dst):
+            lo, hi = d * scale, (d + 1) * scale
+            for s_ in range(int(np.floor(lo)), min(int(np.ceil(hi)), n_src)):
+                M[d, s_] = max(0.0, min(hi, s_ + 1) - max(lo, s_))
+            M[d] /= M[d].sum()
+    else:                      # enlarge: INTER_AREA falls back to its linear variant
+        inv = 1.0 / scale
+        for d in range(n_dst):
+            s_ = int(np.floor(d * scale))
+            fx = (d + 1) - (s_ + 1) * inv
+            fx = 0.0 if fx <= 0 else fx - np.floor(fx)
+            M[d, s_] += 1.0 - fx
+            M[d, min(s_ + 1, n_src - 1)] += fx
+    return M
+
+
+def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
+    """``cv2.resize(img, (W, H), interpolation=cv2.INTER_AREA)`` on uint8.
+    Integer enlargement is pixel replication, integer reduction a box mean."""
+    h, w = img.shape[:2]
+    if (h, w) == (H, W):
+        return img.copy()
+    if H % h == 0 and W % w == 0:
+        return np.repeat(np.repeat(img, H // h, axis=0), W // w, axis=1)
+    My, Mx = _area_matrix(h, H), _area_matrix(w, W)
+    src = img.astype(np.float64)
+    out = My @ src @ Mx.T if src.ndim == 2 else np.einsum("dh,hwc,ew->dec", My, src, Mx)
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+
+
+# ---- security wrapper (single:59-86) -----------------------------------------
+def derive_key(password: str, nonce: bytes) -> bytes:
+    return hashlib.sha256(password.encode("utf-8") + nonce).digest()
+
+
+def rng_from_key(key: bytes) -> np.random.Generator:
+    return np.random.default_rng(int.from_bytes(key[:8], "big", signed=False))
+
+
+def permutation_index(H: int, W: int, key: bytes) -> np.ndarray:
+    """``idx = np.arange(H*W); rng.shuffle(idx)`` (single:68-69,124,219,265):
+    bit-exact because it *is* the same NumPy PCG64 call."""
+    idx = np.arange(H * W)
+    rng_from_key(key).shuffle(idx)
+    return idx
+
+
+def permute(plane: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    H, W = plane.shape[:2]
+    return plane.reshape(-1)[idx].reshape(H, W).astype(np.float32)
+
+
+def unpermute(plane: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    H, W = plane.shape[:2]
+    inv = np.empty_like(idx)
+    inv[idx] = np.arange(idx.size)
+    return plane.reshape(-1)[inv].reshape(H, W)
+
+
+def hmac_digest(key: bytes, arrays) -> bytes:
+    h = _hmac.new(key, b"", hashlib.sha256)
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.digest()
+
+
+def digests_equal(a: bytes, b: bytes) -> bool:
+    return _hmac.compare_digest(a, b)
+
+
+# ---- metrics (single:38-57) ----------------------------------------------------
+def psnr(a: np.ndarray, b: np.ndarray) -> float:
+    a = a.astype(np.float32); b = b.astype(np.float32)
+    mse = float(np.mean((a - b) ** 2))
+    if mse <= 1e-12:
+        return 99.0
+    return float(20.0 * np.log10(255.0 / max(np.sqrt(mse), 1e-12)))
+
+
+_G11 = None
+
+
+def _blur(img: np.ndarray) -> np.ndarray:
+    """cv2.GaussianBlur(img, (11, 11), 1.5), default border REFLECT_101."""
+    global _G11
+    if _G11 is None:
+        x = np.arange(11, dtype=np.float64) - 5.0
+        k = np.exp(-(x * x) / (2 * 1.5 * 1.5))
+        _G11 = (k / k.sum()).astype(np.float32)
+    t = scipy.ndimage.correlate1d(img, _G11, axis=0, mode="mirror")
+    return scipy.ndimage.correlate1d(t, _G11, axis=1, mode="mirror")
+
+
+def ssim(img1: np.ndarray, img2: np.ndarray) -> float:
+    if img1.ndim == 3: img1 = bgr_to_gray(img1)
+    if img2.ndim == 3: img2 = bgr_to_gray(img2)
+    x = img1.astype(np.float32); y = img2.astype(np.float32)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    mx, my = _blur(x), _blur(y)
+    sxx = _blur(x * x) - mx * mx
+    syy = _blur(y * y) - my * my
+    sxy = _blur(x * y) - mx * my
+    num = (2 * mx * my + C1) * (2 * sxy + C2)
+    den = (mx * mx + my * my + C1) * (sxx + syy + C2) + 1e-12
+    return float(np.mean(num / den))
+
+
+def normalize_minmax(x: np.ndarray) -> np.ndarray:
+    """``cv2.normalize(x, None, 0, 255, cv2.NORM_MINMAX)`` (single:221,269-271)."""
+    x = x.astype(np.float32)
+    lo, hi = float(x.min()), float(x.max())
+    scale = 255.0 / (hi - lo) if (hi - lo) > np.finfo(np.float64).eps else 0.0
+    return ((x - np.float32(lo)) * np.float32(scale)).astype(np.float32)
+
+
+def unsharp(img_u8: np.ndarray, amount: float) -> np.ndarray:
+    """The unsharp half of ``_enhance_gray/_enhance_color`` (single:94-96,108-110):
+    GaussianBlur(sigma=1.0) then addWeighted(e, 1+a, blur, -a).  CLAHE and
+    NL-means (OpenCV-only, inside try/except in the reference) are not applied."""
+    f = img_u8.astype(np.float32)
+    sig = (1.0, 1.0) if f.ndim == 2 else (1.0, 1.0, 0.0)
+    blur = scipy.ndimage.gaussian_filter(f, sigma=sig, mode="mirror", truncate=4.0)
+    return np.clip(np.floor((1.0 + amount) * f - amount * blur + 0.5), 0, 255).astype(np.uint8)

@@ -68,7 +68,7 @@ int wm_memcpy_h2d(wm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes
 int wm_memcpy_d2h(wm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int wm_memset(wm_ctx* ctx, void* dst_dev, int value, size_t bytes);
 
-/* HIP-event timing on the context's stream (slot 0..15) */
+/* HIP-event timing on the context's stream (slot 0..63) */
 int wm_event_record(wm_ctx* ctx, int slot);
 int wm_event_elapsed_ms(wm_ctx* ctx, int slot_start, int slot_stop, float* ms_out);
 

@@ -1,0 +1,141 @@
+"""CPU checks of the exact per-tile functions the gfx950 kernels are built
+from (csrc/wm_tile_math.h compiled with g++, tests/host_harness.cpp) against
+the oracle.  The harness is test infrastructure; the product never loads it."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from oracle import wm_oracle as o
+
+SIGMA_RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hh():
+    return C.CDLL(ge.build_host_harness())
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _inputs(H, W, seed=1234):
+    host = np.random.default_rng(seed).integers(0, 256, (H, W), dtype=np.uint8)
+    wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+    return host, wys
+
+
+def _rel(a, b):
+    a = a.reshape(-1, 8); b = b.reshape(-1, 8)
+    return float(np.max(np.abs(a - b) / np.maximum(b[:, :1], 1e-30)))
+
+
+def test_dct8x8_matches_closed_form(hh):
+    t = np.random.default_rng(0).uniform(0, 255, (8, 8)).astype(np.float32)
+    a = t.copy(); hh.hh_dct8x8(vp(a), 0)
+    D = o.dct_basis(8)
+    assert np.abs(a - D @ t @ D.T).max() < 1e-3
+    hh.hh_dct8x8(vp(a), 1)
+    assert np.abs(a - t).max() < 1e-3
+
+
+@pytest.mark.parametrize("variant", ["literal", "packed"])
+@pytest.mark.parametrize("H,W", [(64, 96), (256, 256)])
+def test_embed_tile_math_vs_oracle(hh, variant, H, W):
+    alpha = 0.15
+    host, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, tile=8)
+    nb = (H // 8) * (W // 8)
+    sw = np.ascontiguousarray(ref["Sw"].reshape(nb, 8))
+    stego = np.empty((H, W), np.uint8); sc = np.empty((nb, 8), np.float32); yw = np.empty((H, W), np.float32)
+    ms = C.c_int(0); nf = C.c_int(0)
+    if variant == "literal":
+        hh.hh_embed_tiles_u8(vp(host), vp(sw), vp(stego), vp(sc), vp(yw), H, W, W, C.c_float(alpha), 8, C.byref(ms))
+    else:
+        hh.hh_embed_tiles_u8_pk(vp(host), vp(sw), vp(stego), vp(sc), vp(yw), H, W, W, C.c_float(alpha), 8,
+                                C.byref(ms), C.byref(nf))
+    assert 0 < ms.value <= 7
+    assert _rel(sc, ref["Sc"]) < SIGMA_RTOL
+    d = np.abs(stego.astype(int) - ref["stego"].astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    assert np.abs(yw - ref["Yw"]).max() < 3e-2
+
+
+def test_sigma_svd_extract_tile_math_vs_oracle(hh):
+    H, W, alpha = 128, 160, 0.15
+    host, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, tile=8)
+    nb = (H // 8) * (W // 8)
+    for fn, extra in (("hh_sigma_tiles_u8", ()), ("hh_sigma_tiles_u8_pk", (None,))):
+        s = np.empty((nb, 8), np.float32)
+        getattr(hh, fn)(vp(ref["stego"]), vp(s), H, W, W, *extra)
+        assert _rel(s, o.stego_sigma(ref["stego"].astype(np.float32), 8)) < SIGMA_RTOL
+    U = np.empty((nb, 8, 8), np.float32); S = np.empty((nb, 8), np.float32); Vt = np.empty((nb, 8, 8), np.float32)
+    hh.hh_svd_tiles_f32(vp(wys), vp(U), vp(S), vp(Vt), H, W, W)
+    assert _rel(S, ref["Sw"]) < SIGMA_RTOL
+    rec = np.matmul(U * S[:, None, :], Vt)
+    reco = np.matmul(ref["Uw"].reshape(nb, 8, 8) * ref["Sw"].reshape(nb, 1, 8), ref["Vwt"].reshape(nb, 8, 8))
+    assert np.abs(rec - reco).max() < 5e-3
+    out = np.empty((H, W), np.float32)
+    hh.hh_extract_tiles_u8(vp(ref["stego"]), vp(np.ascontiguousarray(ref["Sc"])), vp(np.ascontiguousarray(ref["Uw"])),
+                           vp(np.ascontiguousarray(ref["Vwt"])), vp(out), H, W, W, C.c_float(alpha), 8)
+    wo = o.extract_plane(ref["stego"].astype(np.float32), ref["Sc"], ref["Uw"], ref["Vwt"], alpha, 0.6, H, W, 8)
+    assert np.abs(out - wo).max() < 2e-2
+
+
+def test_flat_and_smooth_tiles_take_the_literal_path_without_nans(hh):
+    """Rank-deficient tiles (flat / saturated regions) must come out finite and
+    unchanged in their null space; smooth noisy tiles stay within 1 LSB."""
+    H = W = 128
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (128 + 60 * np.sin(xx / 37.0) + 50 * np.cos(yy / 23.0)
+           + np.random.default_rng(5).normal(0, 1.5, (H, W))).clip(0, 255).astype(np.uint8)
+    img[:32, :32] = 200; img[32:64, :32] = 0; img[64:96, :32] = 255
+    wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+    ref = o.embed_plane(img.astype(np.float32), wys, 0.15, 0.6, 8)
+    nb = (H // 8) * (W // 8)
+    sw = np.ascontiguousarray(ref["Sw"].reshape(nb, 8))
+    stego = np.empty((H, W), np.uint8); sc = np.empty((nb, 8), np.float32); yw = np.empty((H, W), np.float32)
+    ms = C.c_int(0); nf = C.c_int(0)
+    hh.hh_embed_tiles_u8_pk(vp(img), vp(sw), vp(stego), vp(sc), vp(yw), H, W, W, C.c_float(0.15), 8,
+                            C.byref(ms), C.byref(nf))
+    assert np.all(np.isfinite(yw)) and np.all(np.isfinite(sc))
+    assert nf.value >= 48                                   # the 3 flat 32x32 regions
+    flat = np.zeros((H, W), bool); flat[:96, :32] = True
+    d = np.abs(stego.astype(int) - ref["stego"].astype(int))
+    assert d[~flat].max() <= 1
+    assert np.abs(sc - ref["Sc"].reshape(nb, 8)).max() < 1e-2
+    # flat tiles: sigma_1 = 8 * value, the rest 0 -> only the DC term moves
+    assert np.ptp(stego[:8, :8].astype(int)) <= 1
+
+
+def test_tile_math_under_sanitizers(tmp_path):
+    """AddressSanitizer + UBSan over the tile arithmetic (CPU build only - GPU
+    sanitizers are not available on this pool)."""
+    exe = str(tmp_path / "hh_asan")
+    main = str(tmp_path / "main.cpp")
+    open(main, "w").write(r'''
+#include <vector>
+#include <cstdio>
+#include <cstdint>
+extern "C" int hh_embed_tiles_u8_pk(const uint8_t*, const float*, uint8_t*, float*, float*, int, int, int, float, int, int*, int*);
+extern "C" int hh_sigma_tiles_u8_pk(const uint8_t*, float*, int, int, int, int*);
+int main() {
+  const int H = 40, W = 56; std::vector<uint8_t> h(H * W), s(H * W); std::vector<float> sw((H/8)*(W/8)*8, 5.f), sc(sw.size()), yw(H * W);
+  unsigned x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = x >> 24; }
+  int ms = 0, nf = 0;
+  hh_embed_tiles_u8_pk(h.data(), sw.data(), s.data(), sc.data(), yw.data(), H, W, W, 0.15f, 8, &ms, &nf);
+  hh_sigma_tiles_u8_pk(s.data(), sc.data(), H, W, W, nullptr);
+  std::printf("ok %d %d\n", ms, nf); return 0; }
+''')
+    src = os.path.join(ge.ROOT, "tests", "host_harness.cpp")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        src, main, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-2000:]

@@ -1,0 +1,78 @@
+"""Frame sharding + the watermark broadcast, on CPU with gloo (world_size 2)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG_NAME
+
+sh = importlib.import_module(PKG_NAME + ".sharding")
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("n", [0, 1, 7, 256, 1000])
+def test_frame_ranges_tile_the_batch(world, n):
+    rs = sh.all_ranges(world, n)
+    assert rs[0][0] == 0 and rs[-1][1] == n
+    for (a0, a1), (b0, b1) in zip(rs, rs[1:]):
+        assert a1 == b0 and a0 <= a1
+    sizes = [b - a for a, b in rs]
+    assert max(sizes) - min(sizes) <= 1
+    if n == 256 and world == 8:
+        assert sizes == [32] * 8                      # BASELINE config 4: 32 frames per rank
+
+
+def test_frame_range_rejects_bad_rank():
+    with pytest.raises(ValueError):
+        sh.frame_range(2, 2, 10)
+    with pytest.raises(ValueError):
+        sh.frame_range(0, 0, 10)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    shm = importlib.import_module(PKG_NAME + ".sharding")
+    from oracle import wm_oracle as o
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, N, alpha = 32, 48, 5, 0.15
+    nt = (H // 8) * (W // 8)
+    Sw = torch.zeros((nt, 8), dtype=torch.float32)
+    U = torch.zeros((nt, 8, 8), dtype=torch.float32); Vt = torch.zeros_like(U)
+    if rank == 0:                                          # rank 0 owns the watermark
+        wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+        u, s, vt = o.watermark_decompose(wys, 8)
+        Sw.copy_(torch.from_numpy(s.reshape(nt, 8))); U.copy_(torch.from_numpy(u.reshape(nt, 8, 8)))
+        Vt.copy_(torch.from_numpy(vt.reshape(nt, 8, 8)))
+    shm.broadcast_watermark([Sw, U, Vt], src=0)
+    lo, hi = shm.frame_range(rank, world, N)
+    psnrs = []
+    for f in range(lo, hi):                                # this rank's frames (CPU stand-in for the kernel)
+        host = np.random.default_rng(1234 + f).integers(0, 256, (H, W), dtype=np.uint8)
+        wm_svd = (U.numpy().reshape(H // 8, W // 8, 8, 8), Sw.numpy().reshape(H // 8, W // 8, 8),
+                  Vt.numpy().reshape(H // 8, W // 8, 8, 8))
+        e = o.embed_plane(host.astype(np.float32), None, alpha, 0.6, 8, wm_svd=wm_svd)
+        psnrs.append(o.psnr(host, e["stego"]))
+    mine = float(np.sum(psnrs))
+    allv = shm.gather_scalars(mine)
+    np.save(os.path.join(tmp, f"r{rank}.npy"), np.array([lo, hi, float(Sw.sum()), allv.sum()]))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_broadcast_and_ranges(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npy"); r1 = np.load(tmp_path / "r1.npy")
+    assert (r0[0], r0[1], r1[0], r1[1]) == (0, 2, 2, 5)
+    assert r0[2] == r1[2] and r0[2] > 0                    # rank 1 received rank 0's singular values
+    assert abs(r0[3] - r1[3]) < 1e-9 and r0[3] > 0         # all-gathered report agrees on both ranks
