@@ -108,7 +108,12 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
 
 
 def _meta_tile(meta) -> Optional[int]:
-    return int(meta["tile"]) if "tile" in meta else None
+    """Tile size a meta was written with: the explicit ``tile`` key, else inferred
+    from the singular-value array (per-tile [nby, nbx, 8] vs full-frame [L])."""
+    if "tile" in meta:
+        return int(meta["tile"])
+    s = meta["Sc"] if "Sc" in meta else meta["Sb"]
+    return TILE if np.asarray(s).ndim == 3 else None
 
 
 def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = True,
