@@ -356,14 +356,19 @@ WM_HD uint32_t quant_u8(float x) {
 // host singular values Sc; when YW is true the unclipped float stego is written
 // through `yw` (row stride `yw_stride` floats).  Returns sweeps; `deficient` is
 // set when the tile must take the literal path instead.
-template <bool YW>
-WM_HD int embed_tile_pk(const RawTile& t, const float (&sw)[8], const float (&alpha_k)[8],
-                        float (&sc)[8], RawTile& out, float* yw, const size_t yw_stride,
-                        bool& deficient) {
-  v2f a[4][8];
-  float n2[8];
+// Phase 1 (registers: B only): B = X V from the raw tile.
+WM_HD int embed_jacobi_pk(const RawTile& t, v2f (&a)[4][8], float (&n2)[8]) {
   raw_to_pk(t, a);
-  const int sweeps = jacobi_cols_pk(a, n2);
+  return jacobi_cols_pk(a, n2);
+}
+
+// Phase 2: singular values out, perturbation, Y = X + B diag(e) B^T X, quantise.
+// The kernel reloads the raw tile and loads sw only now, so nothing but B has
+// to stay live across the sweep loop.
+template <bool YW>
+WM_HD void embed_finish_pk(const RawTile& t, const v2f (&a)[4][8], const float (&n2)[8],
+                           const float (&sw)[8], const float (&alpha_k)[8], float (&sc)[8],
+                           RawTile& out, float* yw, const size_t yw_stride, bool& deficient) {
   deficient = !(n2[7] > SIGMA_RATIO_MIN2 * n2[0]);
   float e[8];                                        // alpha_i sw_i / s_i^3
 #pragma unroll
@@ -372,51 +377,53 @@ WM_HD int embed_tile_pk(const RawTile& t, const float (&sw)[8], const float (&al
     sc[i] = n2[i] * rs;
     e[i] = (alpha_k[i] * sw[i]) * (rs * rs * rs);
   }
-  // Y = X + B G with G = diag(e) (B^T X), done in two column halves (columns
-  // 0-3 -> the lo words, 4-7 -> the hi words) so only half of G is live.
-  // Columns are packed in pairs, g[i][cp] = (G[i][2cp], G[i][2cp+1]); b_i[r] is
-  // one half of a[r>>1][i], broadcast by the packed FMA's op_sel.
+  // Y = X + B G with G = diag(e) (B^T X), one column pair (2 of the 8 columns)
+  // at a time so that only 8 packed registers of G are live next to B:
+  // g[i] = (G[i][2cp], G[i][2cp+1]);  b_i[r] is one half of a[r>>1][i],
+  // broadcast by the packed FMA's op_sel.
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    v2f g[8][2];
+  for (int r = 0; r < 8; ++r) { out.lo[r] = 0u; out.hi[r] = 0u; }
+#pragma unroll
+  for (int cp = 0; cp < 4; ++cp) {
+    const int sh = 16 * (cp & 1);
+    v2f g[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t w = h ? t.hi[r] : t.lo[r];
-      const v2f x0 = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
-      const v2f x1 = {(float)((w >> 16) & 0xffu), (float)(w >> 24)};
+      const uint32_t w = ((cp < 2) ? t.lo[r] : t.hi[r]) >> sh;
+      const v2f x = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const v2f b = splat2(a[r >> 1][i][r & 1]);
-        g[i][0] = (r == 0) ? b * x0 : fma2(b, x0, g[i][0]);
-        g[i][1] = (r == 0) ? b * x1 : fma2(b, x1, g[i][1]);
+        g[i] = (r == 0) ? b * x : fma2(b, x, g[i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const v2f ev = splat2(e[i]);
-      g[i][0] = g[i][0] * ev;
-      g[i][1] = g[i][1] * ev;
-    }
+    for (int i = 0; i < 8; ++i) g[i] = g[i] * splat2(e[i]);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t w = h ? t.hi[r] : t.lo[r];
-      v2f y0 = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
-      v2f y1 = {(float)((w >> 16) & 0xffu), (float)(w >> 24)};
+      const uint32_t w = ((cp < 2) ? t.lo[r] : t.hi[r]) >> sh;
+      v2f y = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const v2f b = splat2(a[r >> 1][i][r & 1]);
-        y0 = fma2(b, g[i][0], y0);
-        y1 = fma2(b, g[i][1], y1);
-      }
+      for (int i = 0; i < 8; ++i) y = fma2(splat2(a[r >> 1][i][r & 1]), g[i], y);
       if (YW) {
-        float* o = yw + (size_t)r * yw_stride + 4 * h;
-        o[0] = y0[0]; o[1] = y0[1]; o[2] = y1[0]; o[3] = y1[1];
+        float* o = yw + (size_t)r * yw_stride + 2 * cp;
+        o[0] = y[0]; o[1] = y[1];
       }
-      const uint32_t q = quant_u8(y0[0]) | (quant_u8(y0[1]) << 8) | (quant_u8(y1[0]) << 16) |
-                         (quant_u8(y1[1]) << 24);
-      if (h) out.hi[r] = q; else out.lo[r] = q;
+      const uint32_t q = (quant_u8(y[0]) | (quant_u8(y[1]) << 8)) << sh;
+      if (cp < 2) out.lo[r] |= q; else out.hi[r] |= q;
     }
   }
+}
+
+// both phases back to back (CPU harness / simple callers)
+template <bool YW>
+WM_HD int embed_tile_pk(const RawTile& t, const float (&sw)[8], const float (&alpha_k)[8],
+                        float (&sc)[8], RawTile& out, float* yw, const size_t yw_stride,
+                        bool& deficient) {
+  v2f a[4][8];
+  float n2[8];
+  const int sweeps = embed_jacobi_pk(t, a, n2);
+  embed_finish_pk<YW>(t, a, n2, sw, alpha_k, sc, out, yw, yw_stride, deficient);
   return sweeps;
 }
 

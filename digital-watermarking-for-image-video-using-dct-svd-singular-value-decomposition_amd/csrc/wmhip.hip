@@ -228,6 +228,17 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
   const size_t plane = blockIdx.y;
   const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
 
+  wm::v2f a[4][8];
+  float n2[8];
+  int sweeps;
+  {
+    wm::RawTile raw;
+    load_raw<ALIGNED>(host + off, g.row_stride, raw);
+    sweeps = wm::embed_jacobi_pk(raw, a, n2);
+  }
+  // Only B (64 VGPRs) crosses the sweep loop: the raw tile is re-read (L2) and
+  // the watermark sigma loaded only now, instead of being spilled to scratch.
+  asm volatile("" ::: "memory");
   wm::RawTile raw, out;
   float sw[8], sc[8], alpha_k[8];
   load_raw<ALIGNED>(host + off, g.row_stride, raw);
@@ -235,9 +246,8 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
 #pragma unroll
   for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
   float* ywp = YW ? yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8 : nullptr;
-
   bool deficient;
-  const int sweeps = wm::embed_tile_pk<YW>(raw, sw, alpha_k, sc, out, ywp, (size_t)g.W, deficient);
+  wm::embed_finish_pk<YW>(raw, a, n2, sw, alpha_k, sc, out, ywp, (size_t)g.W, deficient);
   const unsigned long long dmask = __builtin_amdgcn_ballot_w64(deficient);
   if (dmask != 0ull) {
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==

@@ -21,7 +21,8 @@ TILE = 8
 ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwmhip.so")
+# WMHIP_LIB selects another build of the same HIP library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("WMHIP_LIB") or os.path.join(_HERE, "csrc", "libwmhip.so")
 
 
 class WmLibraryError(ImportError):
