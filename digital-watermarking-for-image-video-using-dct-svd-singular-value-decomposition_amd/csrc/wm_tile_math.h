@@ -469,6 +469,73 @@ WM_HD int embed_tile(float (&a)[8][8], const float (&sw)[8], const float (&alpha
   return sweeps;
 }
 
+// ---- rank-deficient tiles: deterministic orthonormal completion ---------------
+// A flat / saturated tile has singular values that are exactly 0; its singular
+// vectors there are arbitrary (LAPACK returns *some* orthonormal completion) but
+// the scheme still injects alpha*sw_i along them (single:175-176).  One-sided
+// Jacobi resolves directions to high *relative* accuracy, so adding
+// COMPLETION_DELTA x a fixed full-rank pattern (cond 3.7) to the DCT tile makes
+// U and V complete orthonormal bases; the pattern is subtracted again after
+// the reconstruction, so the output moves by O(eps), not O(delta).
+constexpr float COMPLETION_DELTA = 6.103515625e-05f;   // 2^-14
+constexpr float COMPLETION_PATTERN[8][8] = {
+  {-0.371394f, -0.079717f, -0.983650f, -0.554458f, -0.658720f, -0.953876f, +0.008741f, +0.773822f},
+  {+0.770895f, +0.280528f, -0.063239f, +0.001315f, +0.675874f, -0.488476f, +0.610478f, +0.151159f},
+  {+0.434160f, -0.517163f, -0.154770f, +0.779245f, -0.744333f, +0.573436f, +0.871420f, -0.682901f},
+  {-0.025223f, -0.797351f, +0.189486f, -0.674952f, -0.442962f, +0.883550f, -0.294998f, +0.418505f},
+  {-0.560398f, +0.910414f, +0.028949f, -0.670469f, -0.276553f, +0.424304f, +0.871431f, -0.253670f},
+  {-0.405084f, +0.378566f, +0.483330f, +0.296345f, -0.562919f, -0.634010f, -0.141621f, +0.624869f},
+  {+0.385623f, -0.252198f, +0.255703f, +0.219000f, -0.437414f, -0.709251f, -0.041911f, -0.468894f},
+  {+0.789973f, +0.864080f, -0.920759f, -0.063243f, +0.524377f, -0.040678f, +0.003126f, -0.226323f}};
+
+WM_HD void add_completion(float (&a)[8][8], const float scale) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[r][c] = ffma(scale, COMPLETION_PATTERN[r][c], a[r][c]);
+}
+
+// literal chain on a (possibly) rank-deficient tile: dct2 -> (+delta P) -> svd
+// with V -> U diag(S + alpha Sw) V^T -> (-delta P) -> idct2
+WM_HD int embed_tile_completed(float (&a)[8][8], const float (&sw)[8], const float (&alpha_k)[8],
+                               float (&sc)[8]) {
+  float v[8][8], n2[8], vn2[8];
+  dct8x8(a);
+  add_completion(a, COMPLETION_DELTA);
+  const int sweeps = jacobi_svd8<true>(a, v, n2, vn2);
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float nb = fsqrt(n2[i]), nv = fsqrt(vn2[i]);
+    const float sig = nb * frcp(nv);
+    sc[i] = sig;
+    const float sp = ffma(alpha_k[i], sw[i], sig);
+    const float den = nb * nv;
+    f[i] = (den > 0.0f) ? sp * frcp(den) : 0.0f;
+  }
+  float cw[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float bs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bs[i] = a[r][i] * f[i];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float s = bs[0] * v[c][0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) s = ffma(bs[i], v[c][i], s);
+      cw[r][c] = s;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[r][c] = cw[r][c];
+  add_completion(a, -COMPLETION_DELTA);
+  idct8x8(a);
+  return sweeps;
+}
+
 // ---- sigma only (extract / detect): tile -> singular values -----------------
 WM_HD int sigma_tile(float (&a)[8][8], float (&s)[8]) {
   float n2[8], vn2[8];
@@ -481,9 +548,10 @@ WM_HD int sigma_tile(float (&a)[8][8], float (&s)[8]) {
 
 // ---- full SVD of a float tile (watermark side): U, S, Vt --------------------
 // u[r][i], vt[i][c]; columns with sigma == 0 get u_i = 0.
-WM_HD int svd_tile(float (&a)[8][8], float (&s)[8], float (&vt)[8][8]) {
+WM_HD int svd_tile(float (&a)[8][8], float (&s)[8], float (&vt)[8][8], const bool complete = false) {
   float v[8][8], n2[8], vn2[8];
   dct8x8(a);
+  if (complete) add_completion(a, COMPLETION_DELTA);
   const int sweeps = jacobi_svd8<true>(a, v, n2, vn2);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

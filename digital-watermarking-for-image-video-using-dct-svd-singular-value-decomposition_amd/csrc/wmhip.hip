@@ -215,8 +215,8 @@ __device__ __forceinline__ bool tile_coords(const Geom& g, int& t, int& ty, int&
 // K1  fused embed   (a1 a2 a3 a4 a5 a6 a7; sigma_c side output)
 // ---------------------------------------------------------------------------
 // Fast path: packed, V-free, pixel-domain (wm_tile_math.h identities (1),(2)).
-// Waves that contain a flat / rank-deficient tile append their id to
-// `fb_list` (fb_count = status[1]) and are redone by k_embed_fallback.
+// Flat / rank-deficient tiles append their id to `fb_list` (count = status[1])
+// and are redone by k_embed_fallback.
 template <bool ALIGNED, bool YW>
 __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
     const uint8_t* host, const float* __restrict__ sigma_w,
@@ -248,12 +248,17 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
   float* ywp = YW ? yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8 : nullptr;
   bool deficient;
   wm::embed_finish_pk<YW>(raw, a, n2, sw, alpha_k, sc, out, ywp, (size_t)g.W, deficient);
+  // deficient tiles are appended (wave-aggregated) to the fallback list
   const unsigned long long dmask = __builtin_amdgcn_ballot_w64(deficient);
   if (dmask != 0ull) {
-    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) ==
-        (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
-      const int slot = atomicAdd(status + 1, 1);
-      fb_list[slot] = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned leader = (unsigned)__builtin_ctzll(dmask);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(status + 1, (int)__builtin_popcountll(dmask));
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (deficient) {
+      const unsigned rank = (unsigned)__builtin_popcountll(dmask & ((1ull << lane) - 1ull));
+      fb_list[base + rank] = (uint32_t)(plane * g.n_tiles + t);
     }
   }
   if (sweeps < 0) atomicOr(status, 1);
@@ -261,20 +266,20 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
   store_raw<ALIGNED>(stego + off, g.row_stride, out);
 }
 
-// Literal chain (dct2 -> svd with V -> U diag(S') V^T -> idct2) for the waves
-// listed by the fast kernel.  Persistent-style: a fixed grid strides the list.
+// Literal chain with orthonormal completion (wm::embed_tile_completed) for the
+// tiles listed by the fast kernel; one listed tile per lane, a fixed grid
+// strides the list (count is only known on the device).
 template <bool ALIGNED, bool YW>
 __global__ __launch_bounds__(WAVE, 2) void k_embed_fallback(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const unsigned waves_per_plane) {
+    int* __restrict__ status, const uint32_t* __restrict__ fb_list) {
   const int count = status[1];
-  for (int it = blockIdx.x; it < count; it += gridDim.x) {
-    const unsigned wid = fb_list[it];
-    const size_t plane = wid / waves_per_plane;
-    const int t = (int)(wid % waves_per_plane) * WAVE + threadIdx.x;
-    if (t >= g.n_tiles) continue;
+  for (int it = blockIdx.x * WAVE + threadIdx.x; it < count; it += gridDim.x * WAVE) {
+    const uint32_t id = fb_list[it];
+    const size_t plane = id / (uint32_t)g.n_tiles;
+    const int t = (int)(id % (uint32_t)g.n_tiles);
     const int ty = t / g.nbx, tx = t - ty * g.nbx;
     const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
     float a[8][8], sw[8], sc[8], alpha_k[8];
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_embed_fallback(
     load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
 #pragma unroll
     for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
-    if (wm::embed_tile(a, sw, alpha_k, sc) < 0) atomicOr(status, 1);
+    if (wm::embed_tile_completed(a, sw, alpha_k, sc) < 0) atomicOr(status, 1);
     store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
     store_tile_u8<ALIGNED>(stego + off, g.row_stride, a);
     if (YW) {
@@ -347,6 +352,24 @@ __global__ __launch_bounds__(WAVE, 2) void k_svd_tiles(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 8; ++r) load_row8_f32<VECF>(p + (size_t)r * g.row_stride, a[r]);
   if (wm::svd_tile(a, s, vt) < 0) atomicOr(status, 1);
+  // rank-deficient watermark tiles: redo with the completion pattern so that Uw
+  // stays a full orthonormal basis (rare: wave-uniform branch)
+  const bool deficient = !(s[7] > 1e-5f * s[0]);
+  if (wm::wave_any(deficient)) {
+    float a2[8][8], s2[8], vt2[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_row8_f32<VECF>(p + (size_t)r * g.row_stride, a2[r]);
+    if (wm::svd_tile(a2, s2, vt2, true) < 0) atomicOr(status, 1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      s[r] = deficient ? s2[r] : s[r];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        a[r][c] = deficient ? a2[r][c] : a[r][c];
+        vt[r][c] = deficient ? vt2[r][c] : vt[r][c];
+      }
+    }
+  }
   const size_t ti = plane * g.n_tiles + t;
   store_row8_f32<true>(S + ti * 8, s);
   store_mat_f32(U + ti * 64, a);
@@ -680,8 +703,10 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
       return set_err(WM_ERR_BADARG, "sigma arrays must be 16-byte aligned");
     const bool al = u8_aligned(host, stego, row_stride, plane_stride);
     const dim3 grid = tile_grid(g, n_planes), block(WAVE);
-    const size_t n_waves = (size_t)grid.x * grid.y;
-    WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, n_waves * sizeof(uint32_t), "fallback list"));
+    const size_t n_all = (size_t)g.n_tiles * (size_t)n_planes;
+    if (n_all > 0xffffffffull) return set_err(WM_ERR_BADARG, "more than 2^32 tiles in one call");
+    const size_t n_waves = (n_all + WAVE - 1) / WAVE;
+    WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, n_all * sizeof(uint32_t), "fallback list"));
     WM_HIP(hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int), ctx->stream));
     uint32_t* fb = (uint32_t*)ctx->fb_list;
     const dim3 fgrid((unsigned)(n_waves < 2048 ? n_waves : 2048));
@@ -690,8 +715,7 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
     hipLaunchKernelGGL((k_embed_tiles<A, Y>), grid, block, 0, ctx->stream, host, sigma_w, stego,   \
                        sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb);         \
     hipLaunchKernelGGL((k_embed_fallback<A, Y>), fgrid, block, 0, ctx->stream, host, sigma_w,      \
-                       stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb,   \
-                       grid.x);                                                                    \
+                       stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb);  \
   } while (0)
     if (al && yw) WM_LAUNCH_EMBED(true, true);
     else if (al) WM_LAUNCH_EMBED(true, false);

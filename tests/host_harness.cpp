@@ -67,6 +67,11 @@ int hh_svd_tiles_f32(const float* plane, float* U, float* S, float* Vt, int H, i
       for (int r = 0; r < 8; ++r)
         for (int c = 0; c < 8; ++c) a[r][c] = plane[(size_t)(ty * 8 + r) * row_stride + tx * 8 + c];
       svd_tile(a, s, vt);
+      if (!(s[7] > 1e-5f * s[0])) {   // rank-deficient: orthonormal completion, like k_svd_tiles
+        for (int r = 0; r < 8; ++r)
+          for (int c = 0; c < 8; ++c) a[r][c] = plane[(size_t)(ty * 8 + r) * row_stride + tx * 8 + c];
+        svd_tile(a, s, vt, true);
+      }
       for (int i = 0; i < 8; ++i) S[t * 8 + i] = s[i];
       for (int r = 0; r < 8; ++r)
         for (int c = 0; c < 8; ++c) {
@@ -137,7 +142,7 @@ int hh_embed_tiles_u8_pk(const uint8_t* host, const float* sigma_w, uint8_t* ste
       if (deficient) {
         ++nf;
         raw_to_f32(raw, y);
-        s = embed_tile(y, sw, alpha_k, sc);
+        s = embed_tile_completed(y, sw, alpha_k, sc);
         for (int r = 0; r < 8; ++r) {
           out.lo[r] = quant_u8(y[r][0]) | (quant_u8(y[r][1]) << 8) | (quant_u8(y[r][2]) << 16) | (quant_u8(y[r][3]) << 24);
           out.hi[r] = quant_u8(y[r][4]) | (quant_u8(y[r][5]) << 8) | (quant_u8(y[r][6]) << 16) | (quant_u8(y[r][7]) << 24);

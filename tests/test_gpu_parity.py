@@ -109,3 +109,25 @@ def test_empty_and_bad_args(gpu_ctx):
         gpu_ctx.embed_tiles(np.zeros((8, 8), np.uint8), np.zeros((1, 1, 8), np.float32), 0.1, K=9)
     with pytest.raises(ValueError):
         gpu_ctx.embed_tiles(np.zeros((8, 8), np.float32), np.zeros((1, 1, 8), np.float32), 0.1)
+
+
+def test_rank_deficient_tiles_on_gpu(gpu_ctx):
+    """Flat / saturated / rank-1 / rank-2 tiles go through the fallback kernel's
+    orthonormal completion: same property checks as the CPU build of the math."""
+    from test_host_harness import _degenerate_image, check_completion_properties
+    img, mask = _degenerate_image()
+    H, W = img.shape
+    wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+    ref = o.embed_plane(img.astype(np.float32), wys, 0.15, 0.6, 8)
+    stego, sc, yw = gpu_ctx.embed_tiles(img, ref["Sw"], 0.15, want_yw=True)
+    check_completion_properties(img, mask, wys, 0.15, stego, sc, yw, ref)
+    # all-flat plane: every tile takes the fallback path
+    flat = np.full((64, 64), 77, np.uint8)
+    st, sc2, yw2 = gpu_ctx.embed_tiles(flat, ref["Sw"][:8, :8], 0.15, want_yw=True)
+    assert np.isfinite(yw2).all() and abs(float(sc2[0, 0, 0]) - 77 * 8) < 1e-2
+    # watermark side: degenerate plane keeps orthonormal factors
+    wflat = np.zeros((16, 16), np.float32); wflat[:8, :8] = 255; wflat[8:, 8:] = np.arange(8)[None, :]
+    U, S, Vt = gpu_ctx.svd_tiles(wflat)
+    I = np.eye(8, dtype=np.float32)
+    assert np.abs(np.matmul(U.swapaxes(-1, -2), U) - I).max() < 1e-5
+    assert np.abs(np.matmul(Vt, Vt.swapaxes(-1, -2)) - I).max() < 1e-5

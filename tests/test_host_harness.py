@@ -88,14 +88,46 @@ def test_sigma_svd_extract_tile_math_vs_oracle(hh):
     assert np.abs(out - wo).max() < 2e-2
 
 
-def test_flat_and_smooth_tiles_take_the_literal_path_without_nans(hh):
-    """Rank-deficient tiles (flat / saturated regions) must come out finite and
-    unchanged in their null space; smooth noisy tiles stay within 1 LSB."""
-    H = W = 128
+def _degenerate_image(H=128, W=128):
+    """flat, saturated, rank-1, rank-2 and smooth-noisy regions in one plane"""
     yy, xx = np.mgrid[0:H, 0:W]
     img = (128 + 60 * np.sin(xx / 37.0) + 50 * np.cos(yy / 23.0)
            + np.random.default_rng(5).normal(0, 1.5, (H, W))).clip(0, 255).astype(np.uint8)
     img[:32, :32] = 200; img[32:64, :32] = 0; img[64:96, :32] = 255
+    img[96:, :32] = (np.arange(32, dtype=np.uint8) * 3)[None, :]                       # rank 1
+    img[96:, 32:64] = (np.arange(32)[:, None] * 5 + np.arange(32)[None, :] * 2).astype(np.uint8)   # rank 2
+    mask = np.zeros((H, W), bool); mask[:, :32] = True; mask[96:, 32:64] = True
+    return img, mask
+
+
+def check_completion_properties(img, mask, wys, alpha, stego, sc, yw, ref):
+    """Rank-deficient tiles have no unique singular vectors, so parity with LAPACK's
+    arbitrary completion is undefined; what IS defined is checked instead:
+    sigma(Yw tile) = Sc + alpha*Sw, Sc = the tile's true singular values, the
+    injected energy, and 1-LSB parity everywhere else."""
+    H, W = img.shape
+    nb = (H // 8) * (W // 8)
+    sw = ref["Sw"].reshape(nb, 8).astype(np.float64)
+    assert np.all(np.isfinite(yw)) and np.all(np.isfinite(sc))
+    d = np.abs(stego.astype(int) - ref["stego"].astype(int))
+    assert d[~mask].max() <= 1
+    T = o.to_tiles(yw).reshape(nb, 8, 8).astype(np.float64)
+    X = o.to_tiles(img.astype(np.float64)).reshape(nb, 8, 8)
+    sx = np.linalg.svd(X, compute_uv=False)
+    scf = sc.reshape(nb, 8).astype(np.float64)
+    # exact zeros come out as delta * sigma(pattern) <= 4 * 2^-14 by construction
+    assert np.max((np.abs(scf - sx) - 4 * 2.0 ** -14) / np.maximum(sx[:, :1], 1.0)) < 1e-5
+    want = np.sort(scf + alpha * sw, axis=1)[:, ::-1]
+    got = np.linalg.svd(T, compute_uv=False)
+    assert np.max(np.abs(got - want) / np.maximum(want[:, :1], 1.0)) < 1e-4
+    inj = np.sqrt(((T - X) ** 2).sum((1, 2)))
+    assert np.max(np.abs(inj - alpha * np.sqrt((sw ** 2).sum(1))) / inj) < 1e-3
+    assert np.array_equal(stego, np.clip(yw, 0, 255).astype(np.uint8))
+
+
+def test_rank_deficient_tiles_get_an_orthonormal_completion(hh):
+    img, mask = _degenerate_image()
+    H, W = img.shape
     wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
     ref = o.embed_plane(img.astype(np.float32), wys, 0.15, 0.6, 8)
     nb = (H // 8) * (W // 8)
@@ -104,14 +136,17 @@ def test_flat_and_smooth_tiles_take_the_literal_path_without_nans(hh):
     ms = C.c_int(0); nf = C.c_int(0)
     hh.hh_embed_tiles_u8_pk(vp(img), vp(sw), vp(stego), vp(sc), vp(yw), H, W, W, C.c_float(0.15), 8,
                             C.byref(ms), C.byref(nf))
-    assert np.all(np.isfinite(yw)) and np.all(np.isfinite(sc))
-    assert nf.value >= 48                                   # the 3 flat 32x32 regions
-    flat = np.zeros((H, W), bool); flat[:96, :32] = True
-    d = np.abs(stego.astype(int) - ref["stego"].astype(int))
-    assert d[~flat].max() <= 1
-    assert np.abs(sc - ref["Sc"].reshape(nb, 8)).max() < 1e-2
-    # flat tiles: sigma_1 = 8 * value, the rest 0 -> only the DC term moves
-    assert np.ptp(stego[:8, :8].astype(int)) <= 1
+    assert nf.value >= 16 * 4 + 8                      # 4 flat/rank-1 column blocks + rank-2 block
+    check_completion_properties(img, mask, wys, 0.15, stego, sc, yw, ref)
+    # watermark-side SVD of a degenerate plane: U, Vt stay orthonormal and reconstruct the DCT tile
+    wflat = np.zeros((16, 16), np.float32); wflat[:8, :8] = 255; wflat[8:, 8:] = np.arange(8)[None, :]
+    U = np.empty((4, 8, 8), np.float32); S = np.empty((4, 8), np.float32); Vt = np.empty((4, 8, 8), np.float32)
+    hh.hh_svd_tiles_f32(vp(wflat), vp(U), vp(S), vp(Vt), 16, 16, 16)
+    I = np.eye(8)
+    assert np.abs(np.matmul(U.transpose(0, 2, 1), U) - I).max() < 1e-5
+    assert np.abs(np.matmul(Vt, Vt.transpose(0, 2, 1)) - I).max() < 1e-5
+    C0 = o._dct_tiles(o.to_tiles(wflat)).reshape(4, 8, 8)
+    assert np.abs(np.matmul(U * S[:, None, :], Vt) - C0).max() < 1e-3
 
 
 def test_tile_math_under_sanitizers(tmp_path):
