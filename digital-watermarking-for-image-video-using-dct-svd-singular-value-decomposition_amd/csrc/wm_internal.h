@@ -1,0 +1,52 @@
+// Internal declarations shared by the translation units of libwmhip.so
+// (wmhip.hip: tile-mode kernels + context; wm_ref.hip: full-frame mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/wmhip.h"
+
+namespace wmi {
+
+constexpr int WAVE = 64;
+constexpr int N_EVENTS = 64;
+
+int set_err(int code, const char* fmt, const char* a = "", const char* b = "");
+
+#define WM_HIP(call)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) return wmi::set_err(WM_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define WM_TRY(call)              \
+  do {                            \
+    int rc_ = (call);             \
+    if (rc_ != WM_OK) return rc_; \
+  } while (0)
+
+}  // namespace wmi
+
+struct wm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  int* d_status = nullptr;        // [0] sticky kernel status, [1] embed fallback count
+  void* scratch = nullptr;        // grow-only device scratch (host-pointer wrappers)
+  size_t scratch_bytes = 0;
+  void* partials = nullptr;       // grow-only detect partial sums
+  size_t partials_bytes = 0;
+  void* fb_list = nullptr;        // grow-only list of tiles for the embed fallback
+  size_t fb_bytes = 0;
+  void* ref_ws = nullptr;         // grow-only workspace of the full-frame mode
+  size_t ref_ws_bytes = 0;
+  float* dct_mat[2] = {nullptr, nullptr};   // cached DCT-II basis matrices (device), by size
+  int dct_n[2] = {0, 0};
+  hipEvent_t ev[wmi::N_EVENTS] = {};
+};
+
+namespace wmi {
+// grow-only device buffer (synchronises the stream before freeing the old one)
+int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what);
+}  // namespace wmi

@@ -1,0 +1,675 @@
+// Full-frame ("reference semantics", tile=None) mode of the DCT-SVD watermark
+// on gfx950: ONE dense SVD per plane instead of one per 8x8 tile
+// (app_dct_svd_single.py:172-177 embed, :205-218 extract, :297-301 detect).
+//
+// Algorithm:
+//  * the orthonormal DCT cancels (svd(D_H Y D_W^T) = (D_H Ux) S (D_W Vx)^T), so
+//    embed/sigma/detect work on the pixel plane itself;
+//  * block one-sided Jacobi on the SHORT side: A (L x M, L <= M; the plane or
+//    its transpose) is augmented with the identity, Aug = [A | I_L]; row
+//    rotations turn it into [B | Qt] with B = Qt A having mutually orthogonal
+//    rows, |b_i| = sigma_i, Qt^T = left singular vectors.  Rows are processed in
+//    blocks of RB: a step takes disjoint block pairs (round-robin tournament),
+//    forms each pair's 2RB x 2RB Gram matrix (k_rf_gram), runs one cyclic
+//    two-sided Jacobi sweep on it in LDS (k_rf_inner -> rotation block R) and
+//    applies R^T to the 2RB rows of Aug as a small GEMM (k_rf_apply);
+//  * embed is V-free: Yw = Y + Q diag(alpha*sw_rank(i) / sigma_i) B.
+// DCT-domain factors (watermark side / extract) use plain tiled SGEMMs with the
+// DCT basis matrices.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "wm_internal.h"
+
+using namespace wmi;
+
+namespace {
+
+constexpr int RB = 32;        // rows per Jacobi block
+constexpr int RP = 2 * RB;    // rows per block pair
+constexpr int GRAM_CC = 128;  // columns per Gram partial
+constexpr int MAX_SWEEPS = 40;
+constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to ~eps*sqrt(M)
+
+// ---------------------------------------------------------------------------
+// generic row-major SGEMM:  C = alpha * op(A) op(B) + beta * C
+// 64x64 tile, 256 threads, 4x4 per thread, K step 16.  Plain-library-GEMM
+// shaped work (DCT as two GEMMs, U diag V^T products); not the hot loop.
+// ---------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_sgemm(const int M, const int N, const int K, const float alpha,
+                                              const float* __restrict__ A, const int lda,
+                                              const float* __restrict__ B, const int ldb,
+                                              const float beta, float* __restrict__ C, const int ldc) {
+  __shared__ __attribute__((aligned(16))) float As[16][68];   // [k][m]
+  __shared__ __attribute__((aligned(16))) float Bs[16][68];   // [k][n]
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int bm = blockIdx.y * 64, bn = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i;
+      int m, k;
+      if (TA) { k = e >> 6; m = e & 63; } else { m = e >> 4; k = e & 15; }
+      const int gm = bm + m, gk = k0 + k;
+      float v = 0.0f;
+      if (gm < M && gk < K) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+      As[k][m] = v;
+      int n, kb;
+      if (TB) { n = e >> 4; kb = e & 15; } else { kb = e >> 6; n = e & 63; }
+      const int gn = bn + n, gkb = k0 + kb;
+      float w = 0.0f;
+      if (gn < N && gkb < K) w = TB ? B[(size_t)gn * ldb + gkb] : B[(size_t)gkb * ldb + gn];
+      Bs[kb][n] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = bm + ty * 4 + i;
+    if (gm >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = bn + tx * 4 + j;
+      if (gn >= N) continue;
+      float* c = C + (size_t)gm * ldc + gn;
+      *c = (beta == 0.0f) ? alpha * acc[i][j] : __builtin_fmaf(beta, *c, alpha * acc[i][j]);
+    }
+  }
+}
+
+int sgemm(wm_ctx* ctx, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda,
+          const float* B, int ldb, float beta, float* C, int ldc) {
+  if (M <= 0 || N <= 0) return WM_OK;
+  const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+  if (ta && tb) hipLaunchKernelGGL((k_sgemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  else if (ta) hipLaunchKernelGGL((k_sgemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  else if (tb) hipLaunchKernelGGL((k_sgemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  else hipLaunchKernelGGL((k_sgemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Aug = [A | I]:  A[i][j] = src(i, j) (or src(j, i) when `transpose`), rows
+// i >= L are zero padding; the identity block is Lp x Lp.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_rf_load(const T* __restrict__ src, const size_t src_stride, const int transpose,
+                          float* __restrict__ aug, const int ld, const int L, const int Lp, const int M) {
+  const int i = blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M + Lp; j += gridDim.x * blockDim.x) {
+    float v;
+    if (j < M) v = (i < L) ? (float)(transpose ? src[(size_t)j * src_stride + i] : src[(size_t)i * src_stride + j]) : 0.0f;
+    else v = (j - M == i) ? 1.0f : 0.0f;
+    aug[(size_t)i * ld + j] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Gram partials: for pair p = (I, J) and column chunk ch,
+//   partial[p][ch][r][c] = sum_{k in chunk} X[r][k] X[c][k],  X = rows of blocks I,J
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, const int ld, const int M,
+                                                const int2* __restrict__ pairs, float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) float Xt[32][68];   // [k][row]
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int p = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
+  const int2 pr = pairs[p];
+  const int c_begin = ch * GRAM_CC, c_end = min(M, c_begin + GRAM_CC);
+  float acc[4][4] = {};
+  for (int c0 = c_begin; c0 < c_end; c0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = t + 256 * i;             // 64 rows x 32 cols
+      const int r = e >> 5, k = e & 31;
+      const int grow = (r < RB) ? pr.x * RB + r : pr.y * RB + (r - RB);
+      const int gc = c0 + k;
+      Xt[k][r] = (gc < c_end) ? aug[(size_t)grow * ld + gc] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      const float4 a = *reinterpret_cast<const float4*>(&Xt[kk][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Xt[kk][tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  float* out = partials + ((size_t)p * nch + ch) * RP * RP;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<float4*>(&out[(ty * 4 + i) * RP + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+}
+
+// ---------------------------------------------------------------------------
+// One cyclic two-sided Jacobi sweep on the pair's 64x64 Gram matrix in LDS.
+// Parallel (round-robin) ordering: 63 steps x 32 disjoint rotations; de Rijk
+// rule per rotation (larger diagonal entry to the lower index).  Outputs the
+// accumulated rotation block R (G' = R^T G R) and the sweep-wide maximum of
+// |G_rc| / sqrt(G_rr G_cc) (convergence measure, before rotating).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rr_elem(const int pos, const int step) {
+  // round-robin tournament over 64 players: position 0 is fixed, the others rotate
+  return pos == 0 ? 0 : ((pos - 1 - step) % 63 + 63) % 63 + 1;
+}
+
+__global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ partials, const int nch,
+                                                 float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits) {
+  __shared__ float G[RP][RP + 1];
+  __shared__ float R[RP][RP + 1];
+  __shared__ float Cs[32], Ss[32];
+  __shared__ int Ps[32], Qs[32];
+  __shared__ float red[4];
+  const int t = threadIdx.x, p = blockIdx.x;
+  const float* src = partials + (size_t)p * nch * RP * RP;
+  for (int e = t; e < RP * RP; e += 256) {
+    float s = 0.0f;
+    for (int ch = 0; ch < nch; ++ch) s += src[(size_t)ch * RP * RP + e];
+    G[e >> 6][e & 63] = s;
+    R[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  float mx = 0.0f;
+  for (int e = t; e < RP * RP; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if (r != c) {
+      const float d = G[r][r] * G[c][c];
+      if (d > 0.0f) mx = fmaxf(mx, fabsf(G[r][c]) * __builtin_amdgcn_rsqf(d));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+  if ((t & 63) == 0) red[t >> 6] = mx;
+  __syncthreads();
+  if (t == 0) atomicMax(maxcos_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+
+  for (int step = 0; step < RP - 1; ++step) {
+    if (t < 32) {
+      int a = rr_elem(t, step), b = rr_elem(RP - 1 - t, step);
+      const int pp = min(a, b), qq = max(a, b);
+      const float app = G[pp][pp], aqq = G[qq][qq], apq = G[pp][qq];
+      const float tau = aqq - app, g2 = apq + apq;
+      const float h = sqrtf(fmaf(tau, tau, g2 * g2));
+      const float den = fabsf(tau) + h;
+      float tt = (den > 0.0f) ? g2 / den : 0.0f;
+      tt = (tau < 0.0f) ? -tt : tt;
+      const float c = 1.0f / sqrtf(fmaf(tt, tt, 1.0f)), s = c * tt;
+      const bool sw = tau > 0.0f;
+      Cs[t] = sw ? s : c;
+      Ss[t] = sw ? -c : s;
+      Ps[t] = pp; Qs[t] = qq;
+    }
+    __syncthreads();
+    // column rotations of G and R:  X[:, p], X[:, q] <- C x_p - S x_q,  S x_p + C x_q
+    for (int e = t; e < RP * 32; e += 256) {
+      const int k = e & 31, r = e >> 5;
+      const int pp = Ps[k], qq = Qs[k];
+      const float C = Cs[k], S = Ss[k];
+      const float gp = G[r][pp], gq = G[r][qq];
+      G[r][pp] = C * gp - S * gq; G[r][qq] = S * gp + C * gq;
+      const float rp = R[r][pp], rq = R[r][qq];
+      R[r][pp] = C * rp - S * rq; R[r][qq] = S * rp + C * rq;
+    }
+    __syncthreads();
+    // row rotations of G
+    for (int e = t; e < RP * 32; e += 256) {
+      const int k = e >> 6, c = e & 63;
+      const int pp = Ps[k], qq = Qs[k];
+      const float C = Cs[k], S = Ss[k];
+      const float gp = G[pp][c], gq = G[qq][c];
+      G[pp][c] = C * gp - S * gq; G[qq][c] = S * gp + C * gq;
+    }
+    __syncthreads();
+  }
+  float* out = Rout + (size_t)p * RP * RP;
+  for (int e = t; e < RP * RP; e += 256) out[e] = R[e >> 6][e & 63];
+}
+
+// ---------------------------------------------------------------------------
+// Aug rows of the pair <- R^T x rows, one 64-column tile per workgroup.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rf_apply(float* __restrict__ aug, const int ld, const int ncols,
+                                                 const int2* __restrict__ pairs, const float* __restrict__ Rall) {
+  __shared__ __attribute__((aligned(16))) float Rs[RP][68];   // [k][i]
+  __shared__ __attribute__((aligned(16))) float Xs[RP][68];   // [k][c]
+  const int t = threadIdx.x, tc = t & 15, ti = t >> 4;
+  const int p = blockIdx.x, c0 = blockIdx.y * 64;
+  const int2 pr = pairs[p];
+  const float* Rp = Rall + (size_t)p * RP * RP;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = t + 256 * i;
+    const int k = e >> 6, c = e & 63;
+    Rs[k][c] = Rp[e];
+    const int grow = (k < RB) ? pr.x * RB + k : pr.y * RB + (k - RB);
+    const int gc = c0 + c;
+    Xs[k][c] = (gc < ncols) ? aug[(size_t)grow * ld + gc] : 0.0f;
+  }
+  __syncthreads();
+  float acc[4][4] = {};
+#pragma unroll 8
+  for (int k = 0; k < RP; ++k) {
+    const float4 r = *reinterpret_cast<const float4*>(&Rs[k][ti * 4]);
+    const float4 x = *reinterpret_cast<const float4*>(&Xs[k][tc * 4]);
+    const float rv[4] = {r.x, r.y, r.z, r.w}, xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(rv[i], xv[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = ti * 4 + i;
+    const int grow = (k < RB) ? pr.x * RB + k : pr.y * RB + (k - RB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gc = c0 + tc * 4 + j;
+      if (gc < ncols) aug[(size_t)grow * ld + gc] = acc[i][j];
+    }
+  }
+}
+
+// squared norms of the B part (first M columns) and the Qt part of every row
+__global__ __launch_bounds__(256) void k_rf_rownorms(const float* __restrict__ aug, const int ld, const int M,
+                                                    const int Lp, double* __restrict__ b2, double* __restrict__ q2) {
+  __shared__ double red[2][4];
+  const int i = blockIdx.x, t = threadIdx.x;
+  const float* row = aug + (size_t)i * ld;
+  double sb = 0.0, sq = 0.0;
+  for (int j = t; j < M; j += 256) sb += (double)row[j] * (double)row[j];
+  for (int j = t; j < Lp; j += 256) sq += (double)row[M + j] * (double)row[M + j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sb += __shfl_down(sb, o, 64); sq += __shfl_down(sq, o, 64); }
+  if ((t & 63) == 0) { red[0][t >> 6] = sb; red[1][t >> 6] = sq; }
+  __syncthreads();
+  if (t == 0) {
+    b2[i] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q2[i] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// rows of the B part scaled in place:  B[i][:] *= d[i]
+__global__ void k_rf_scale_rows(float* __restrict__ aug, const int ld, const int M, const float* __restrict__ d) {
+  const int i = blockIdx.y;
+  const float s = d[i];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x)
+    aug[(size_t)i * ld + j] *= s;
+}
+
+// Yw (float, logical A layout L x M or its transpose) -> clip/truncate -> uint8 plane; optional float copy
+__global__ void k_rf_quant(const float* __restrict__ yw, const int ldy, const int transpose,
+                           uint8_t* __restrict__ dst, const size_t dst_stride, float* __restrict__ ywout,
+                           const int H, const int W) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x) {
+    const float v = transpose ? yw[(size_t)c * ldy + r] : yw[(size_t)r * ldy + c];
+    if (ywout) ywout[(size_t)r * W + c] = v;
+    dst[(size_t)r * dst_stride + c] = (uint8_t)(unsigned)fminf(fmaxf(v, 0.0f), 255.0f);
+  }
+}
+
+// gather sorted, normalised factors:  out[k][:] = src_row[order[k]][:] * scale[k]
+__global__ void k_rf_gather_rows(const float* __restrict__ src, const int ld, const int ncols,
+                                 const int* __restrict__ order, const float* __restrict__ scale,
+                                 float* __restrict__ dst, const int ldd) {
+  const int k = blockIdx.y;
+  const float* row = src + (size_t)order[k] * ld;
+  const float s = scale[k];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ncols; j += gridDim.x * blockDim.x)
+    dst[(size_t)k * ldd + j] = row[j] * s;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct RefPlan {
+  int H, W, L, M, Lp, ld, nbk, npairs, nsteps, nch;
+  bool transpose;        // A = plane^T (portrait planes: the short side must index rows)
+};
+
+RefPlan make_plan(int H, int W) {
+  RefPlan p;
+  p.H = H; p.W = W;
+  p.transpose = H > W;
+  p.L = std::min(H, W); p.M = std::max(H, W);
+  p.Lp = (p.L + RP - 1) / RP * RP;
+  p.ld = (p.M + p.Lp + 3) & ~3;
+  p.nbk = p.Lp / RB; p.npairs = p.nbk / 2; p.nsteps = p.nbk - 1;
+  p.nch = (p.M + GRAM_CC - 1) / GRAM_CC;
+  return p;
+}
+
+struct RefWs {           // carved out of ctx->ref_ws
+  float* aug; float* partials; float* R; int2* pairs; unsigned* maxcos; double* b2; double* q2;
+  float* dvec; int* order; float* scale; float* tmp1; float* tmp2;
+};
+
+inline size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, size_t extra_f32_b) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += a256(bytes); return o; };
+  const size_t o_aug = take((size_t)p.Lp * p.ld * 4), o_par = take((size_t)p.npairs * p.nch * RP * RP * 4),
+               o_R = take((size_t)p.npairs * RP * RP * 4), o_pairs = take((size_t)p.nsteps * p.npairs * sizeof(int2)),
+               o_mc = take(256), o_b2 = take((size_t)p.Lp * 8), o_q2 = take((size_t)p.Lp * 8),
+               o_d = take((size_t)p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
+               o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
+  WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
+  char* b = (char*)ctx->ref_ws;
+  w.aug = (float*)(b + o_aug); w.partials = (float*)(b + o_par); w.R = (float*)(b + o_R);
+  w.pairs = (int2*)(b + o_pairs); w.maxcos = (unsigned*)(b + o_mc); w.b2 = (double*)(b + o_b2);
+  w.q2 = (double*)(b + o_q2); w.dvec = (float*)(b + o_d); w.order = (int*)(b + o_ord);
+  w.scale = (float*)(b + o_sc); w.tmp1 = (float*)(b + o_t1); w.tmp2 = (float*)(b + o_t2);
+  return WM_OK;
+}
+
+int upload_pairs(wm_ctx* ctx, const RefPlan& p, const RefWs& w) {
+  std::vector<int2> tab((size_t)p.nsteps * p.npairs);
+  std::vector<int> idx(p.nbk);
+  std::iota(idx.begin(), idx.end(), 0);
+  for (int s = 0; s < p.nsteps; ++s) {
+    for (int k = 0; k < p.npairs; ++k) {
+      const int a = idx[k], b = idx[p.nbk - 1 - k];
+      tab[(size_t)s * p.npairs + k] = make_int2(std::min(a, b), std::max(a, b));
+    }
+    const int last = idx[p.nbk - 1];
+    for (int j = p.nbk - 1; j > 1; --j) idx[j] = idx[j - 1];
+    idx[1] = last;
+  }
+  WM_HIP(hipMemcpyAsync(w.pairs, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));     // tab is a local
+  return WM_OK;
+}
+
+// orthonormal DCT-II basis D_n (float64 on the host, rounded to float32), cached per context
+int get_dct(wm_ctx* ctx, int n, int slot, float** out) {
+  if (ctx->dct_n[slot] == n && ctx->dct_mat[slot]) { *out = ctx->dct_mat[slot]; return WM_OK; }
+  const int other = 1 - slot;
+  if (ctx->dct_n[other] == n && ctx->dct_mat[other]) { *out = ctx->dct_mat[other]; return WM_OK; }
+  if (ctx->dct_mat[slot]) { WM_HIP(hipStreamSynchronize(ctx->stream)); WM_HIP(hipFree(ctx->dct_mat[slot])); ctx->dct_mat[slot] = nullptr; ctx->dct_n[slot] = 0; }
+  if (hipMalloc((void**)&ctx->dct_mat[slot], (size_t)n * n * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(WM_ERR_NOMEM, "hipMalloc failed for %s", "DCT basis");
+  }
+  std::vector<float> D((size_t)n * n);
+  const double pi = 3.14159265358979323846;
+  for (int k = 0; k < n; ++k) {
+    const double s = (k == 0) ? sqrt(1.0 / n) : sqrt(2.0 / n);
+    for (int m = 0; m < n; ++m) D[(size_t)k * n + m] = (float)(s * cos(pi * (2.0 * m + 1.0) * k / (2.0 * n)));
+  }
+  WM_HIP(hipMemcpyAsync(ctx->dct_mat[slot], D.data(), D.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->dct_n[slot] = n;
+  *out = ctx->dct_mat[slot];
+  return WM_OK;
+}
+
+// block one-sided Jacobi on Aug (already loaded); on return rows of B are orthogonal.
+// sweeps_out: sweeps used (negative: bound hit).
+int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int* sweeps_out) {
+  const int ncols = with_q ? p.M + p.Lp : p.M;
+  int sweep = 0;
+  bool done = false;
+  while (!done && sweep < MAX_SWEEPS) {
+    WM_HIP(hipMemsetAsync(w.maxcos, 0, sizeof(unsigned), ctx->stream));
+    for (int s = 0; s < p.nsteps; ++s) {
+      const int2* pr = w.pairs + (size_t)s * p.npairs;
+      hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, pr, w.partials);
+      hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs), dim3(256), 0, ctx->stream, w.partials, p.nch, w.R, w.maxcos);
+      hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (ncols + 63) / 64), dim3(256), 0, ctx->stream, w.aug, p.ld, ncols, pr, w.R);
+    }
+    WM_HIP(hipGetLastError());
+    unsigned bits = 0;
+    WM_HIP(hipMemcpyAsync(&bits, w.maxcos, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    float mc; memcpy(&mc, &bits, 4);
+    ++sweep;
+    done = mc < CONV_COS;
+  }
+  *sweeps_out = done ? sweep : -sweep;
+  return WM_OK;
+}
+
+// sigma_i = |b_i| / |q_i| for the L_p rows, sort descending -> order, sigma_sorted
+int sorted_sigma(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std::vector<double>& b2,
+                 std::vector<double>& q2, std::vector<int>& order, std::vector<float>& sig) {
+  hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, with_q ? p.Lp : 0, w.b2, w.q2);
+  WM_HIP(hipGetLastError());
+  b2.resize(p.Lp); q2.resize(p.Lp);
+  WM_HIP(hipMemcpyAsync(b2.data(), w.b2, (size_t)p.Lp * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipMemcpyAsync(q2.data(), w.q2, (size_t)p.Lp * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  if (!with_q) std::fill(q2.begin(), q2.end(), 1.0);
+  std::vector<double> s(p.Lp);
+  for (int i = 0; i < p.Lp; ++i) s[i] = sqrt(b2[i] / (q2[i] > 0 ? q2[i] : 1.0));
+  order.resize(p.Lp);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return s[a] > s[b]; });
+  sig.resize(p.L);
+  for (int k = 0; k < p.L; ++k) sig[k] = (float)s[order[k]];
+  return WM_OK;
+}
+
+int check_ref_args(wm_ctx* ctx, const void* plane, int H, int W, int row_stride) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
+  if (!plane) return set_err(WM_ERR_BADARG, "plane pointer is NULL");
+  if (row_stride < W) return set_err(WM_ERR_BADARG, "row_stride < W");
+  return WM_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI (host-pointer entry points; see include/wmhip.h)
+// ===========================================================================
+extern "C" {
+
+int wm_ref_sigma_u8(wm_ctx* ctx, const uint8_t* plane, float* sigma, int H, int W, int row_stride) {
+  WM_TRY(check_ref_args(ctx, plane, H, W, row_stride));
+  if (!sigma) return set_err(WM_ERR_BADARG, "sigma is NULL");
+  const RefPlan p = make_plan(H, W);
+  RefWs w;
+  const size_t n_in = (size_t)H * row_stride;
+  WM_TRY(plan_workspace(ctx, p, w, (n_in + 3) / 4, 0));
+  WM_TRY(upload_pairs(ctx, p, w));
+  uint8_t* d_in = (uint8_t*)w.tmp1;
+  WM_HIP(hipMemcpyAsync(d_in, plane, n_in, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
+                     p.transpose ? 1 : 0, w.aug, p.ld, p.L, p.Lp, p.M);
+  int sweeps = 0;
+  WM_TRY(jacobi_rows(ctx, p, w, false, &sweeps));
+  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
+  std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
+  WM_TRY(sorted_sigma(ctx, p, w, false, b2, q2, order, sig));
+  memcpy(sigma, sig.data(), (size_t)p.L * 4);
+  return WM_OK;
+}
+
+int wm_ref_embed_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,
+                    float* yw, int H, int W, int row_stride, float alpha, int K) {
+  WM_TRY(check_ref_args(ctx, host, H, W, row_stride));
+  if (!sigma_w || !stego || !sigma_c) return set_err(WM_ERR_BADARG, "NULL argument");
+  const RefPlan p = make_plan(H, W);
+  if (K < 0 || K > p.L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
+  RefWs w;
+  const size_t n_in = (size_t)H * row_stride;
+  // tmp1: uint8 input + output planes; tmp2: Yw (float, A layout L x M)
+  WM_TRY(plan_workspace(ctx, p, w, (2 * n_in + 7) / 4 + (yw ? (size_t)H * W : 0), (size_t)p.L * p.M));
+  WM_TRY(upload_pairs(ctx, p, w));
+  uint8_t* d_in = (uint8_t*)w.tmp1;
+  uint8_t* d_out = d_in + ((n_in + 15) & ~(size_t)15);
+  float* d_ywout = yw ? (float*)(d_out + ((n_in + 15) & ~(size_t)15)) : nullptr;
+  float* d_yw = w.tmp2;
+  WM_HIP(hipMemcpyAsync(d_in, host, n_in, hipMemcpyHostToDevice, ctx->stream));
+  if (stego != host) WM_HIP(hipMemcpyAsync(d_out, stego, n_in, hipMemcpyHostToDevice, ctx->stream));
+  else WM_HIP(hipMemcpyAsync(d_out, d_in, n_in, hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
+                     p.transpose ? 1 : 0, w.aug, p.ld, p.L, p.Lp, p.M);
+  // Yw starts as A itself (exactly the pixels): copy the first L rows of the B part before rotating
+  WM_HIP(hipMemcpy2DAsync(d_yw, (size_t)p.M * 4, w.aug, (size_t)p.ld * 4, (size_t)p.M * 4, p.L,
+                          hipMemcpyDeviceToDevice, ctx->stream));
+  int sweeps = 0;
+  WM_TRY(jacobi_rows(ctx, p, w, true, &sweeps));
+  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
+  std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
+  WM_TRY(sorted_sigma(ctx, p, w, true, b2, q2, order, sig));
+  memcpy(sigma_c, sig.data(), (size_t)p.L * 4);
+  // d_i = alpha * sw[rank(i)] / (sigma_i |q_i|^2), rank < K        (S_[:K] = Sc[:K] + alpha*Sw[:K])
+  std::vector<float> d(p.Lp, 0.0f);
+  for (int k = 0; k < std::min(K, p.L); ++k) {
+    const int i = order[k];
+    const double den = sqrt(b2[i] * q2[i]);        // sigma_i * |q_i|^2 = |b_i| |q_i|
+    d[i] = den > 0.0 ? (float)((double)alpha * (double)sigma_w[k] / den) : 0.0f;
+  }
+  WM_HIP(hipMemcpyAsync(w.dvec, d.data(), (size_t)p.Lp * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, p.Lp), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, w.dvec);
+  // Yw += Qt^T (diag(d) B):   [L x Lp]^T-view of Qt (rows i, cols r < L) times [Lp x M]
+  WM_TRY(sgemm(ctx, true, false, p.L, p.M, p.Lp, 1.0f, w.aug + p.M, p.ld, w.aug, p.ld, 1.0f, d_yw, p.M));
+  hipLaunchKernelGGL(k_rf_quant, dim3(8, H), dim3(256), 0, ctx->stream, d_yw, p.M, p.transpose ? 1 : 0, d_out,
+                     (size_t)row_stride, d_ywout, H, W);
+  WM_HIP(hipGetLastError());
+  WM_HIP(hipMemcpyAsync(stego, d_out, n_in, hipMemcpyDeviceToHost, ctx->stream));
+  if (yw) WM_HIP(hipMemcpyAsync(yw, d_ywout, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+// thin SVD of dct2(plane) (apply_dct != 0) or of the plane itself: U [H x L], S [L], Vt [L x W]
+int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* Vt, int H, int W,
+                   int row_stride, int apply_dct) {
+  WM_TRY(check_ref_args(ctx, plane, H, W, row_stride));
+  if (!U || !S || !Vt) return set_err(WM_ERR_BADARG, "U/S/Vt is NULL");
+  const RefPlan p = make_plan(H, W);
+  RefWs w;
+  const size_t n_in = (size_t)H * row_stride;
+  // tmp1: input plane, then sorted factor for download; tmp2: DCT intermediate
+  WM_TRY(plan_workspace(ctx, p, w, std::max(n_in, (size_t)p.M * p.L) + (size_t)H * W, (size_t)H * W));
+  WM_TRY(upload_pairs(ctx, p, w));
+  float* d_in = w.tmp1;
+  float* d_c = w.tmp1 + std::max(n_in, (size_t)p.M * p.L);     // H x W
+  WM_HIP(hipMemcpyAsync(d_in, plane, n_in * 4, hipMemcpyHostToDevice, ctx->stream));
+  const float* src = d_in; size_t src_stride = (size_t)row_stride;
+  if (apply_dct) {
+    float *dH, *dW;
+    WM_TRY(get_dct(ctx, H, 0, &dH));
+    WM_TRY(get_dct(ctx, W, 1, &dW));
+    WM_TRY(sgemm(ctx, false, false, H, W, H, 1.0f, dH, H, d_in, row_stride, 0.0f, w.tmp2, W));   // D_H X
+    WM_TRY(sgemm(ctx, false, true, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_c, W));              // (D_H X) D_W^T
+    src = d_c; src_stride = (size_t)W;
+  }
+  hipLaunchKernelGGL((k_rf_load<float>), dim3(8, p.Lp), dim3(256), 0, ctx->stream, src, src_stride,
+                     p.transpose ? 1 : 0, w.aug, p.ld, p.L, p.Lp, p.M);
+  int sweeps = 0;
+  WM_TRY(jacobi_rows(ctx, p, w, true, &sweeps));
+  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
+  std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
+  WM_TRY(sorted_sigma(ctx, p, w, true, b2, q2, order, sig));
+  memcpy(S, sig.data(), (size_t)p.L * 4);
+  // short-side factor: columns q_i/|q_i|   (rows of Qt), long-side factor: rows b_i/|b_i|
+  std::vector<float> sq(p.L), sb(p.L);
+  for (int k = 0; k < p.L; ++k) {
+    const int i = order[k];
+    sq[k] = q2[i] > 0 ? (float)(1.0 / sqrt(q2[i])) : 0.0f;
+    sb[k] = b2[i] > 0 ? (float)(1.0 / sqrt(b2[i])) : 0.0f;
+  }
+  WM_HIP(hipMemcpyAsync(w.order, order.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
+  // long-side factor rows [L x M]
+  float* d_f = w.tmp1;
+  WM_HIP(hipMemcpyAsync(w.scale, sb.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, w.order, w.scale, d_f, p.M);
+  std::vector<float> longf((size_t)p.L * p.M), shortf((size_t)p.L * p.L);
+  WM_HIP(hipMemcpyAsync(longf.data(), d_f, longf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  WM_HIP(hipMemcpyAsync(w.scale, sq.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, w.aug + p.M, p.ld, p.L, w.order, w.scale, d_f, p.L);
+  WM_HIP(hipMemcpyAsync(shortf.data(), d_f, shortf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  // shortf[k][r] = k-th singular vector of the short side at coordinate r; longf[k][c] likewise
+  if (!p.transpose) {      // A = X: U[r][k] = shortf[k][r] (H x L), Vt[k][c] = longf[k][c] (L x W)
+    for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) U[(size_t)r * p.L + k] = shortf[(size_t)k * p.L + r];
+    memcpy(Vt, longf.data(), longf.size() * 4);
+  } else {                 // A = X^T: U[r][k] = longf[k][r] (H x L), Vt[k][c] = shortf[k][c] (L x W)
+    for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) U[(size_t)r * p.L + k] = longf[(size_t)k * p.M + r];
+    memcpy(Vt, shortf.data(), shortf.size() * 4);
+  }
+  return WM_OK;
+}
+
+// extract: sigma(stego) -> Sw_hat -> Uw[:L,:L] diag(Sw_hat) Vwt[:L,:L], zero-padded -> idct2
+int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw, const float* Vwt,
+                      float* out, int H, int W, int row_stride, float alpha, int K) {
+  WM_TRY(check_ref_args(ctx, stego, H, W, row_stride));
+  if (!sigma_c || !Uw || !Vwt || !out) return set_err(WM_ERR_BADARG, "NULL argument");
+  const int L = std::min(H, W);
+  if (K < 0 || K > L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
+  std::vector<float> s_cw(L);
+  WM_TRY(wm_ref_sigma_u8(ctx, stego, s_cw.data(), H, W, row_stride));          // single:205
+  const float a = fmaxf(alpha, 1e-8f);
+  std::vector<float> sh(L, 0.0f);
+  for (int i = 0; i < K; ++i) sh[i] = (s_cw[i] - sigma_c[i]) / a;                // single:212-213
+  // Wm_hat[:L,:L] = (Uw[:L,:L] * sh) @ Vwt[:L,:L]                              single:214 (the [:L,:L] quirk)
+  const RefPlan p = make_plan(H, W);
+  RefWs w;
+  WM_TRY(plan_workspace(ctx, p, w, (size_t)L * L * 2 + (size_t)H * W, (size_t)H * W));
+  float* d_us = w.tmp1; float* d_v = w.tmp1 + (size_t)L * L; float* d_full = w.tmp1 + (size_t)2 * L * L;
+  std::vector<float> us((size_t)L * L), vv((size_t)L * L);
+  for (int r = 0; r < L; ++r)
+    for (int k = 0; k < L; ++k) us[(size_t)r * L + k] = Uw[(size_t)r * L + k] * sh[k];   // Uw is H x L, rows < L
+  for (int k = 0; k < L; ++k) memcpy(&vv[(size_t)k * L], &Vwt[(size_t)k * W], (size_t)L * 4);
+  WM_HIP(hipMemcpyAsync(d_us, us.data(), us.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipMemcpyAsync(d_v, vv.data(), vv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipMemsetAsync(d_full, 0, (size_t)H * W * 4, ctx->stream));            // single:215
+  WM_TRY(sgemm(ctx, false, false, L, L, L, 1.0f, d_us, L, d_v, L, 0.0f, d_full, W));   // single:216-217
+  float *dH, *dW;
+  WM_TRY(get_dct(ctx, H, 0, &dH));
+  WM_TRY(get_dct(ctx, W, 1, &dW));
+  // idct2(X) = D_H^T X D_W                                                      single:218
+  WM_TRY(sgemm(ctx, true, false, H, W, H, 1.0f, dH, H, d_full, W, 0.0f, w.tmp2, W));
+  WM_TRY(sgemm(ctx, false, false, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_full, W));
+  WM_HIP(hipMemcpyAsync(out, d_full, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+// detect: _nc(Sw[:L], (S_cw - Sc) / max(alpha, 1e-8))     single:297-301, 284-289
+int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
+                     double* score, int H, int W, int row_stride, float alpha) {
+  WM_TRY(check_ref_args(ctx, stego, H, W, row_stride));
+  if (!sigma_c || !sigma_w || !score) return set_err(WM_ERR_BADARG, "NULL argument");
+  const int L = std::min(H, W);
+  std::vector<float> s_cw(L);
+  WM_TRY(wm_ref_sigma_u8(ctx, stego, s_cw.data(), H, W, row_stride));
+  const float a = fmaxf(alpha, 1e-8f);
+  double sa = 0, sb = 0;
+  std::vector<double> x(L), y(L);
+  for (int i = 0; i < L; ++i) { x[i] = sigma_w[i]; y[i] = (double)((s_cw[i] - sigma_c[i]) / a); sa += x[i]; sb += y[i]; }
+  sa /= L; sb /= L;
+  double cov = 0, va = 0, vb = 0;
+  for (int i = 0; i < L; ++i) { const double dx = x[i] - sa, dy = y[i] - sb; cov += dx * dy; va += dx * dx; vb += dy * dy; }
+  *score = cov / (sqrt(va) * sqrt(vb) + 1e-8);
+  return WM_OK;
+}
+
+}  // extern "C"

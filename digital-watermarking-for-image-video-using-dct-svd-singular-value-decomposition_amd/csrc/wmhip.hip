@@ -16,51 +16,19 @@
 #include <string.h>
 #include <new>
 
-#include "../../include/wmhip.h"
+#include "wm_internal.h"
 #include "wm_tile_math.h"
 
-namespace {
+using namespace wmi;
 
-constexpr int WAVE = 64;
-constexpr int N_EVENTS = 64;
-constexpr int N_SUMS = 5;          // detect: sum a, b, ab, aa, bb
+namespace wmi {
 
 thread_local char g_err[512] = "";
 
-int set_err(int code, const char* fmt, const char* a = "", const char* b = "") {
+int set_err(int code, const char* fmt, const char* a, const char* b) {
   snprintf(g_err, sizeof(g_err), fmt, a, b);
   return code;
 }
-
-#define WM_HIP(call)                                                                          \
-  do {                                                                                        \
-    hipError_t e_ = (call);                                                                   \
-    if (e_ != hipSuccess) return set_err(WM_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
-  } while (0)
-
-#define WM_TRY(call)            \
-  do {                          \
-    int rc_ = (call);           \
-    if (rc_ != WM_OK) return rc_; \
-  } while (0)
-
-}  // namespace
-
-struct wm_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool owns_stream = false;
-  int* d_status = nullptr;        // sticky kernel status word
-  void* scratch = nullptr;        // grow-only device scratch (host-pointer wrappers)
-  size_t scratch_bytes = 0;
-  void* partials = nullptr;       // grow-only detect partial sums
-  size_t partials_bytes = 0;
-  void* fb_list = nullptr;        // grow-only list of waves for the embed fallback
-  size_t fb_bytes = 0;
-  hipEvent_t ev[N_EVENTS] = {};
-};
-
-namespace {
 
 int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what) {
   if (bytes <= *have) return WM_OK;
@@ -79,6 +47,12 @@ int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what) 
   *have = want;
   return WM_OK;
 }
+
+}  // namespace wmi
+
+namespace {
+
+constexpr int N_SUMS = 5;          // detect: sum a, b, ab, aa, bb
 
 // ---------------------------------------------------------------------------
 // tile I/O (per lane)
@@ -569,7 +543,7 @@ inline size_t plane_span(int n_planes, int H, int row_stride, size_t plane_strid
 extern "C" {
 
 int wm_abi_version(void) { return WM_ABI_VERSION; }
-const char* wm_last_error(void) { return g_err; }
+const char* wm_last_error(void) { return wmi::g_err; }
 
 int wm_device_count(int* n_out) {
   if (!n_out) return set_err(WM_ERR_BADARG, "n_out is NULL");
@@ -613,6 +587,8 @@ int wm_destroy(wm_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->partials) (void)hipFree(ctx->partials);
   if (ctx->fb_list) (void)hipFree(ctx->fb_list);
+  if (ctx->ref_ws) (void)hipFree(ctx->ref_ws);
+  for (int i = 0; i < 2; ++i) if (ctx->dct_mat[i]) (void)hipFree(ctx->dct_mat[i]);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return WM_OK;

@@ -68,6 +68,11 @@ SIGNATURES = {
     "wm_reconstruct_tiles": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "wm_detect_tiles_u8_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f],
     "wm_detect_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f],
+    "wm_ref_embed_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
+    "wm_ref_sigma_u8": [_vp, _vp, _vp, _i, _i, _i],
+    "wm_ref_svd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
+    "wm_ref_detect_u8": [_vp, _vp, _vp, _vp, C.POINTER(C.c_double), _i, _i, _i, _f],
 }
 
 
@@ -329,3 +334,65 @@ class Context:
         self._call("wm_detect_tiles_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
                    _vp(scores.ctypes.data), n, H, W, rs, ps, nby * nbx * 8 if per_plane else 0, float(alpha))
         return scores
+
+    # ---- full-frame mode (tile=None), one plane per call -----------------------
+    def ref_embed(self, host: np.ndarray, sigma_w: np.ndarray, alpha: float, K: int, want_yw: bool = False):
+        if host.dtype != np.uint8 or host.ndim != 2:
+            raise ValueError("host plane must be uint8 [H, W]")
+        host = np.ascontiguousarray(host)
+        H, W = host.shape
+        L = min(H, W)
+        sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
+        if sw.shape != (L,):
+            raise ValueError(f"sigma_w must have shape ({L},)")
+        stego = np.empty_like(host); sc = np.empty(L, np.float32)
+        yw = np.empty((H, W), np.float32) if want_yw else None
+        self._call("wm_ref_embed_u8", _vp(host.ctypes.data), _vp(sw.ctypes.data), _vp(stego.ctypes.data),
+                   _vp(sc.ctypes.data), _vp(yw.ctypes.data) if want_yw else None, H, W, W, float(alpha), int(K))
+        return stego, sc, yw
+
+    def ref_sigma(self, plane: np.ndarray) -> np.ndarray:
+        if plane.dtype != np.uint8 or plane.ndim != 2:
+            raise ValueError("plane must be uint8 [H, W]")
+        plane = np.ascontiguousarray(plane)
+        H, W = plane.shape
+        s = np.empty(min(H, W), np.float32)
+        self._call("wm_ref_sigma_u8", _vp(plane.ctypes.data), _vp(s.ctypes.data), H, W, W)
+        return s
+
+    def ref_svd(self, plane: np.ndarray, apply_dct: bool = True):
+        if plane.dtype != np.float32 or plane.ndim != 2:
+            raise ValueError("plane must be float32 [H, W]")
+        plane = np.ascontiguousarray(plane)
+        H, W = plane.shape
+        L = min(H, W)
+        U = np.empty((H, L), np.float32); S = np.empty(L, np.float32); Vt = np.empty((L, W), np.float32)
+        self._call("wm_ref_svd_f32", _vp(plane.ctypes.data), _vp(U.ctypes.data), _vp(S.ctypes.data),
+                   _vp(Vt.ctypes.data), H, W, W, 1 if apply_dct else 0)
+        return U, S, Vt
+
+    def ref_extract(self, stego: np.ndarray, sigma_c, Uw, Vwt, alpha: float, K: int) -> np.ndarray:
+        if stego.dtype != np.uint8 or stego.ndim != 2:
+            raise ValueError("stego plane must be uint8 [H, W]")
+        stego = np.ascontiguousarray(stego)
+        H, W = stego.shape
+        L = min(H, W)
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32)
+        Uw = np.ascontiguousarray(Uw, dtype=np.float32); Vwt = np.ascontiguousarray(Vwt, dtype=np.float32)
+        if sc.shape != (L,) or Uw.shape != (H, L) or Vwt.shape != (L, W):
+            raise ValueError("meta arrays do not match the plane size")
+        out = np.empty((H, W), np.float32)
+        self._call("wm_ref_extract_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
+                   _vp(Vwt.ctypes.data), _vp(out.ctypes.data), H, W, W, float(alpha), int(K))
+        return out
+
+    def ref_detect(self, stego: np.ndarray, sigma_c, sigma_w, alpha: float) -> float:
+        if stego.dtype != np.uint8 or stego.ndim != 2:
+            raise ValueError("stego plane must be uint8 [H, W]")
+        stego = np.ascontiguousarray(stego)
+        H, W = stego.shape
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32); sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
+        score = C.c_double(0.0)
+        self._call("wm_ref_detect_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
+                   C.byref(score), H, W, W, float(alpha))
+        return score.value

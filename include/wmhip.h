@@ -152,6 +152,42 @@ int wm_detect_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
                        int n_planes, int H, int W, int row_stride, size_t plane_stride,
                        size_t sigma_w_plane_stride, float alpha);
 
+
+/* ==========================================================================
+ * Full-frame mode ("tile=None", the reference's own semantics): ONE dense
+ * DCT + SVD over the whole plane.  Host-pointer entry points, one plane per
+ * call; L = min(H, W).  Singular values are returned sorted descending like
+ * np.linalg.svd; singular vectors are unique up to sign.
+ * ========================================================================== */
+
+/* Replaces  C = dct2(Y); Uc, Sc, Vct = np.linalg.svd(C); S_[:K] = Sc[:K] +
+ * alpha*Sw[:K]; Cw = Uc @ diag(S_) @ Vct; Yw = idct2(Cw); clip/astype(uint8)
+ * (single:172-177, 27; per colour plane single:127-147).
+ *   sigma_w [L] watermark singular values (sorted), sigma_c [L] out,
+ *   yw optional [H][W] float32 unclipped stego, K in 0..L. */
+int wm_ref_embed_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego,
+                    float* sigma_c, float* yw, int H, int W, int row_stride, float alpha, int K);
+
+/* Replaces  _, S_cw, _ = np.linalg.svd(dct2(Y))  (single:205, 297).  sigma [L]. */
+int wm_ref_sigma_u8(wm_ctx* ctx, const uint8_t* plane, float* sigma, int H, int W, int row_stride);
+
+/* Replaces  Wm = dct2(wy_s); Uw, Sw, Vwt = np.linalg.svd(Wm, full_matrices=False)
+ * (single:173, 131-134) when apply_dct != 0 (plain thin SVD of the plane otherwise).
+ *   U [H][L], S [L], Vt [L][W]. */
+int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* Vt, int H, int W,
+                   int row_stride, int apply_dct);
+
+/* Replaces single:205-218: sigma of the stego -> Sw_hat = (S_cw - Sc)/max(alpha,1e-8),
+ * Sw_hat[K:] = 0 -> Uw[:L,:L] @ diag(Sw_hat) @ Vwt[:L,:L] zero-padded into H x W
+ * (the reference's [:L,:L] truncation on non-square planes is reproduced) -> idct2.
+ *   Uw [H][L], Vwt [L][W], out [H][W] float32. */
+int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                      const float* Vwt, float* out, int H, int W, int row_stride, float alpha, int K);
+
+/* Replaces single:297-301 + _nc (single:284-289): score over all L singular values. */
+int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
+                     double* score, int H, int W, int row_stride, float alpha);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,56 @@
+"""GPU parity of the full-frame mode (tile=None, the reference's own semantics)
+against the oracle: singular values 1e-4 relative (to sigma_1), stego 1 LSB."""
+import numpy as np
+import pytest
+
+from oracle import wm_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(H, W):
+    host = np.random.default_rng(1234).integers(0, 256, (H, W), dtype=np.uint8)
+    wm = np.random.default_rng(4321).integers(0, 256, (H, W), dtype=np.uint8)
+    key = o.derive_key("bench", bytes(8))
+    idx = o.permutation(H, W, o.rng_from_key(key))
+    return host, o.permute(wm.astype(np.float32), idx)
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (64, 96), (96, 64), (200, 328), (512, 512)])
+def test_fullframe_embed_sigma_detect(gpu_ctx, H, W):
+    alpha, kfrac = 0.15, 0.6
+    host, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, kfrac, tile=None)
+    L = min(H, W); K = ref["K"]
+    stego, sc, yw = gpu_ctx.ref_embed(host, ref["Sw"], alpha, K, want_yw=True)
+    assert np.max(np.abs(sc - ref["Sc"])) / ref["Sc"][0] < 1e-4
+    d = np.abs(stego.astype(int) - ref["stego"].astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+    assert np.abs(yw - ref["Yw"]).max() < 2e-2
+    s = gpu_ctx.ref_sigma(ref["stego"])
+    so = o.stego_sigma(ref["stego"].astype(np.float32), None)
+    assert np.max(np.abs(s - so)) / so[0] < 1e-4
+    score = gpu_ctx.ref_detect(ref["stego"], ref["Sc"], ref["Sw"], alpha)
+    assert abs(score - o.detect_plane(ref["stego"].astype(np.float32), ref["Sc"], ref["Sw"], alpha, None)) < 2e-3
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (96, 64), (128, 128)])
+def test_fullframe_watermark_svd_and_extract(gpu_ctx, H, W):
+    alpha = 0.15
+    host, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, tile=None)
+    L = min(H, W)
+    U, S, Vt = gpu_ctx.ref_svd(wys, apply_dct=True)
+    assert np.max(np.abs(S - ref["Sw"])) / ref["Sw"][0] < 1e-4
+    C = o.dct2(wys)
+    assert np.abs(U @ np.diag(S) @ Vt - C).max() < 2e-4 * np.abs(C).max()
+    assert np.abs(U.T @ U - np.eye(L)).max() < 1e-4 and np.abs(Vt @ Vt.T - np.eye(L)).max() < 1e-4
+    # extract with the ORACLE's meta (sign/cluster ambiguity of singular vectors cancels there)
+    w = gpu_ctx.ref_extract(ref["stego"], ref["Sc"], ref["Uw"], ref["Vwt"], alpha, ref["K"])
+    wo = o.extract_plane(ref["stego"].astype(np.float32), ref["Sc"], ref["Uw"], ref["Vwt"], alpha, 0.6, H, W, None)
+    assert np.abs(w - wo).max() < 5e-2 * max(1.0, np.abs(wo).max() / 255)
+    # and a full GPU round trip: GPU meta -> GPU extract correlates with the scrambled watermark
+    st, sc, _ = gpu_ctx.ref_embed(host, S, alpha, ref["K"])
+    w2 = gpu_ctx.ref_extract(st, sc, U, Vt, alpha, ref["K"])
+    hh = min(H, W)
+    assert np.corrcoef(w2[:hh, :hh].ravel(), wo[:hh, :hh].ravel())[0, 1] > 0.98
