@@ -11,9 +11,11 @@ defaults where the reference has a behaviour:
   tile     8 (default): the north_star's block formulation - the reference's
            per-matrix arithmetic applied to every 8x8 tile.
            Its meta carries ``tile=8`` and is not readable by the reference's
-           own full-frame extract.  ``tile=None`` (reference full-frame
-           semantics) has no GPU kernel yet and raises NotImplementedError -
-           there is deliberately no CPU fallback.
+           own full-frame extract.  ``tile=None``: the reference's own
+           full-frame semantics (one DCT + one dense SVD per plane) on the
+           GPU; stego + meta written this way are what the reference's
+           extract/detect expect (same keys, shapes, HMAC coverage).  Neither
+           mode has a CPU fallback.
   k_floor  the literal 8 of ``K = max(8, int(kfrac*L))`` (single:174); at
            tile=8 the formula is 8 for every kfrac, so a mid-band sweep sets
            k_floor < 8.
@@ -50,13 +52,9 @@ def _k_of(L: int, kfrac: float, k_floor: int) -> int:
     return min(L, max(int(k_floor), int(kfrac * L)))     # single:174 (capped at L = 8)
 
 
-def _need_tile(tile):
-    if tile is None:
-        raise NotImplementedError(
-            "tile=None (full-frame reference semantics) has no GPU kernel yet; "
-            "use tile=8.  There is no CPU fallback.")
-    if int(tile) != TILE:
-        raise ValueError("tile must be 8")
+def _check_tile(tile):
+    if tile is not None and int(tile) != TILE:
+        raise ValueError("tile must be 8 or None")
 
 
 # ---------------------------------------------------------------------------
@@ -68,12 +66,14 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
     """cover, wm: BGR uint8.  Returns dict(stego BGR uint8, meta dict, psnr, ssim)."""
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để nhúng.")              # single:115-116
-    _need_tile(tile)
+    _check_tile(tile)
     ctx = _ctx(device)
     H, W = cover.shape[:2]
     wm = hg.resize_area(wm, W, H)                                          # single:118
     key = hg.derive_key(password, nonce)                                   # single:119
     idx = hg.permutation_index(H, W, key)
+    if tile is None:
+        return _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac, k_floor)
     K = _k_of(TILE, kfrac, k_floor)
     common = dict(payload_type="image", shape=np.array((H, W)), alpha=float(alpha),
                   kfrac=float(kfrac), nonce=np.frombuffer(nonce, dtype=np.uint8),
@@ -107,6 +107,44 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
                 ssim=hg.ssim(hg.bgr_to_gray(cover), Yw))                   # single:190
 
 
+def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac, k_floor) -> dict:
+    """tile=None: exactly the reference's meta (keys of single:157-166,183-189, no extras
+    unless k_floor differs from the literal 8)."""
+    H, W = cover.shape[:2]
+    L = min(H, W)
+    K = _k_of(L, kfrac, k_floor)
+    common = dict(payload_type="image", shape=np.array((H, W)), alpha=float(alpha),
+                  kfrac=float(kfrac), nonce=np.frombuffer(nonce, dtype=np.uint8))
+    if k_floor != 8:
+        common["k_floor"] = np.int32(k_floor)
+    if color:
+        meta = dict(mode="color", **common)
+        planes = []
+        for ch, n in enumerate("bgr"):                                     # single:122-147
+            w_s = hg.permute(wm[..., ch].astype(np.float32), idx)
+            U, S, Vt = ctx.ref_svd(w_s, apply_dct=True)                    # single:131-134
+            st, Sc, _ = ctx.ref_embed(np.ascontiguousarray(cover[..., ch]), S, alpha, K)
+            planes.append(st)
+            meta["S" + n] = Sc; meta["UW" + n] = U; meta["VW" + n + "t"] = Vt; meta["SW" + n] = S
+        stego = np.stack(planes, axis=-1)
+        digest = hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"], meta["UWb"], meta["UWg"], meta["UWr"],
+                                      meta["VWbt"], meta["VWgt"], meta["VWrt"]])
+        meta["digest"] = np.frombuffer(digest, dtype=np.uint8)
+        return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego), ssim=hg.ssim(cover, stego))
+    ycc = hg.bgr_to_ycrcb(cover)
+    Y = np.ascontiguousarray(ycc[..., 0])
+    wy_s = hg.permute(hg.bgr_to_gray(wm).astype(np.float32), idx)
+    Uw, Sw, Vwt = ctx.ref_svd(wy_s, apply_dct=True)                        # single:173
+    stegoY, Sc, Yw = ctx.ref_embed(Y, Sw, alpha, K, want_yw=True)          # single:172-177
+    out = ycc.copy(); out[..., 0] = stegoY
+    stego = hg.ycrcb_to_bgr(out)
+    digest = hg.hmac_digest(key, [Sc, Uw, Vwt])
+    meta = dict(mode="gray", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw, **common,
+                digest=np.frombuffer(digest, dtype=np.uint8))
+    return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego),
+                ssim=hg.ssim(hg.bgr_to_gray(cover), Yw))
+
+
 def _meta_tile(meta) -> Optional[int]:
     """Tile size a meta was written with: the explicit ``tile`` key, else inferred
     from the singular-value array (per-tile [nby, nbx, 8] vs full-frame [L])."""
@@ -136,10 +174,12 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
             + [meta["VW" + n + "t"] for n in "bgr"]
     if not hg.digests_equal(hg.hmac_digest(key, parts), digest):
         raise ValueError("Sai mật khẩu hoặc meta không khớp.")             # single:208-209,246-247
-    _need_tile(_meta_tile(meta))
+    tile = _meta_tile(meta)
     ctx = _ctx(device)
-    K = _k_of(TILE, kfrac, k_floor)
     idx = hg.permutation_index(H, W, key)                                  # single:219,265
+    if tile is None:
+        return _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, W, idx, normalize)
+    K = _k_of(TILE, kfrac, k_floor)
     if mode == "gray":
         Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])           # single:204
         wy_s = ctx.extract_tiles(Y, meta["Sc"], meta["Uw"], meta["Vwt"], alpha, K)   # single:205-218
@@ -161,10 +201,43 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
     return np.stack(outs, axis=-1)
 
 
+def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, W, idx, normalize):
+    def k_for(Sc, S_len_u, S_len_v):
+        L = min(len(Sc), min(H, W), S_len_u, S_len_v)                      # single:210
+        return _k_of(L, kfrac, k_floor)
+    if mode == "gray":
+        Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])
+        Uw, Vwt = meta["Uw"], meta["Vwt"]
+        wy_s = ctx.ref_extract(Y, meta["Sc"], Uw, Vwt, alpha, k_for(meta["Sc"], Uw.shape[0], Vwt.shape[0]))
+        wy = hg.unpermute(wy_s, idx)
+        if normalize:
+            wy = hg.normalize_minmax(wy)
+        return np.clip(wy, 0, 255).astype(np.uint8)
+    outs = []
+    for ch, n in enumerate("bgr"):
+        U, Vt, Sc = meta["UW" + n], meta["VW" + n + "t"], meta["S" + n]
+        w_s = ctx.ref_extract(np.ascontiguousarray(stego[..., ch]), Sc, U, Vt, alpha,
+                              k_for(Sc, U.shape[0], Vt.shape[0]))
+        w = hg.unpermute(w_s, idx)
+        if normalize:
+            w = hg.normalize_minmax(w)
+        outs.append(np.clip(w, 0, 255).astype(np.uint8))
+    return np.stack(outs, axis=-1)
+
+
 def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0):
     mode = str(meta["mode"]); alpha = float(meta["alpha"])                 # single:293
-    _need_tile(_meta_tile(meta))
+    tile = _meta_tile(meta)
     ctx = _ctx(device)
+    if tile is None:
+        if mode == "gray":
+            Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])
+            score = ctx.ref_detect(Y, meta["Sc"], meta["Sw"], alpha)       # single:297-301
+            return bool(score >= thresh), float(score)
+        nc = [ctx.ref_detect(np.ascontiguousarray(stego[..., ch]), meta["S" + n], meta["SW" + n], alpha)
+              for ch, n in enumerate("bgr")]                               # single:304-316
+        score = float((nc[0] + nc[1] + nc[2]) / 3.0)
+        return bool(score >= thresh), score
     if mode == "gray":
         Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])           # single:296
         score = float(ctx.detect_tiles(Y, meta["Sc"], meta["Sw"], alpha)[0])   # single:297-301

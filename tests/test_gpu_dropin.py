@@ -11,6 +11,7 @@ from oracle import wm_oracle as o
 pytestmark = pytest.mark.gpu
 
 GOLDEN_T8 = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*_t8*.npz")))
+GOLDEN_REF = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*_ref.npz")))
 
 
 @pytest.fixture(scope="module")
@@ -82,8 +83,8 @@ def test_file_level_roundtrip(core, tmp_path, color):
         core.embed(cp, wp, out, meta, password="")
     with pytest.raises(ValueError):
         core.embed(str(tmp_path / "missing.png"), wp, out, meta, password="pw")
-    with pytest.raises(NotImplementedError):
-        core.embed(cp, wp, out, meta, password="pw", tile=None)
+    with pytest.raises(ValueError):
+        core.embed(cp, wp, out, meta, password="pw", tile=16)
 
 
 def _frob_check(ctx, plane_u8, sigma):
@@ -161,3 +162,45 @@ def test_config5_8k_embed_extract_detect_kfloor_sweep(gpu_ctx):
     w = gpu_ctx.extract_tiles(stego, sc, U, Vt, alpha, K=8)
     assert np.corrcoef(w.ravel()[::31], wys.ravel()[::31])[0, 1] > 0.9
     assert gpu_ctx.detect_tiles(stego, sc, S, alpha)[0] > 0.95
+
+
+@pytest.mark.parametrize("path", GOLDEN_REF, ids=[os.path.basename(p)[:-4] for p in GOLDEN_REF])
+def test_fullframe_golden_fixture_through_the_dropin(core, path):
+    """tile=None: the reference's own semantics.  Files written this way carry exactly
+    the reference's meta keys, so the reference's extract/detect (here: the oracle's
+    restatement of them) read them, and vice versa."""
+    g = np.load(path, allow_pickle=False)
+    nonce = bytes(g["meta_nonce"].tolist())
+    color = bool(g["color"])
+    r = core.embed_arrays(g["cover"], g["wm"], "golden-pw", nonce, float(g["alpha"]), color,
+                          float(g["kfrac"]), None, int(g["k_floor"]))
+    d = np.abs(r["stego"].astype(int) - g["stego"].astype(int))
+    assert d.max() <= (1 if color else 2) and np.mean(d != 0) < 1e-2
+    assert abs(r["psnr"] - float(g["psnr"])) < 5e-2 and abs(r["ssim"] - float(g["ssim"])) < 1e-3
+    want = {"mode", "payload_type", "shape", "alpha", "kfrac", "nonce", "digest"}
+    want |= {"Sb", "Sg", "Sr", "UWb", "VWbt", "SWb", "UWg", "VWgt", "SWg", "UWr", "VWrt", "SWr"} if color \
+        else {"Sc", "Uw", "Vwt", "Sw"}
+    assert set(r["meta"]) == want                                            # single:157-166,183-189
+    for k in ("Sc", "Sw", "Sb", "SWb"):
+        if "meta_" + k in g:
+            a, b = r["meta"][k], g["meta_" + k]
+            assert a.shape == b.shape and np.max(np.abs(a - b)) / b[0] < 1e-4
+    H, W = g["cover"].shape[:2]
+    L = min(H, W)
+    U = r["meta"]["UWb" if color else "Uw"]; Vt = r["meta"]["VWbt" if color else "Vwt"]
+    assert U.shape == (H, L) and Vt.shape == (L, W)
+    # GPU-written files through the oracle's (= reference's) extract / detect
+    ex_o = o.extract_arrays(r["stego"], r["meta"], "golden-pw", True, None, int(g["k_floor"]))
+    ok_o, score_o = o.detect_arrays(r["stego"], r["meta"], 0.6, None)
+    assert ok_o and abs(score_o - float(g["detect_score"])) < 5e-3
+    assert np.mean(np.abs(ex_o.astype(int) - g["extracted"].astype(int)) > 2) < 5e-2
+    # oracle-written (= reference-format) files through the GPU extract / detect
+    if "meta_Uw" in g or "meta_UWb" in g:
+        gm = {k[5:]: g[k] for k in g.files if k.startswith("meta_")}
+        gm["mode"] = "color" if color else "gray"
+        ex_g = core.extract_arrays(g["stego"], gm, "golden-pw", True)
+        assert np.mean(np.abs(ex_g.astype(int) - g["extracted"].astype(int)) > 2) < 5e-2
+        ok, score = core.detect_arrays(g["stego"], gm, 0.6)
+        assert ok and abs(score - float(g["detect_score"])) < 5e-3
+        with pytest.raises(ValueError, match="Sai mật khẩu"):
+            core.extract_arrays(g["stego"], gm, "wrong")

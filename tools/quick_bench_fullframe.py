@@ -1,0 +1,33 @@
+"""Timing of the full-frame (tile=None) entry points vs the oracle (= the
+reference's NumPy/LAPACK path).  Host-pointer API: times include PCIe copies."""
+import argparse, importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+api = importlib.import_module("digital-watermarking-for-image-video-using-dct-svd-singular-value-decomposition_amd.hostapi")
+from oracle import wm_oracle as o
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--H", type=int, default=1080); ap.add_argument("--W", type=int, default=1920)
+ap.add_argument("--cpu", type=int, default=1)
+a = ap.parse_args()
+H, W = a.H, a.W
+host = np.random.default_rng(1234).integers(0, 256, (H, W), dtype=np.uint8)
+wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+ctx = api.Context(0)
+L = min(H, W); K = max(8, int(0.6 * L)); alpha = 0.15
+def t(f, n=2):
+    f(); t0 = time.perf_counter()
+    for _ in range(n): r = f()
+    return (time.perf_counter() - t0) / n, r
+dt, (U, S, Vt) = t(lambda: ctx.ref_svd(wys, True)); print(f"gpu wm svd+dct  {dt*1e3:9.1f} ms", flush=True)
+dt, (st, sc, _) = t(lambda: ctx.ref_embed(host, S, alpha, K)); print(f"gpu embed       {dt*1e3:9.1f} ms", flush=True)
+dt, s = t(lambda: ctx.ref_sigma(st)); print(f"gpu sigma       {dt*1e3:9.1f} ms", flush=True)
+dt, w = t(lambda: ctx.ref_extract(st, sc, U, Vt, alpha, K)); print(f"gpu extract     {dt*1e3:9.1f} ms", flush=True)
+dt, score = t(lambda: ctx.ref_detect(st, sc, S, alpha)); print(f"gpu detect      {dt*1e3:9.1f} ms  score {score:.4f}", flush=True)
+if a.cpu:
+    t0 = time.perf_counter(); e = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, None); t1 = time.perf_counter()
+    print(f"cpu oracle embed (2 SVDs) {(t1-t0)*1e3:9.1f} ms")
+    d = np.abs(st.astype(int) - e["stego"].astype(int))
+    print("parity: sigma rel", float(np.max(np.abs(sc - e["Sc"])) / e["Sc"][0]), "stego max", int(d.max()), "frac", float((d != 0).mean()))
+    t0 = time.perf_counter(); o.extract_plane(e["stego"].astype(np.float32), e["Sc"], e["Uw"], e["Vwt"], alpha, 0.6, H, W, None); t1 = time.perf_counter()
+    print(f"cpu oracle extract        {(t1-t0)*1e3:9.1f} ms")
