@@ -171,23 +171,46 @@ __global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int rr_elem(const int pos, const int step) {
   // round-robin tournament over 64 players: position 0 is fixed, the others rotate
-  return pos == 0 ? 0 : ((pos - 1 - step) % 63 + 63) % 63 + 1;
+  if (pos == 0) return 0;
+  int v = pos - 1 - step;          // step < 63
+  if (v < 0) v += RP - 1;
+  return v + 1;
 }
 
+// cross_only != 0: only the 32 x 32 pairs between the two row blocks are rotated
+// (bipartite schedule, 32 steps); the within-block pairs are covered once per
+// outer sweep by the full 63-step schedule (every block sits in exactly one
+// pair of the sweep's first step).
 __global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ partials, const int nch,
-                                                 float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits) {
-  __shared__ float G[RP][RP + 1];
+                                                 float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits,
+                                                 const int cross_only) {
+  __shared__ float GG[2][RP][RP + 1];   // double-buffered: a step reads one copy, writes the other
+  float (*G)[RP + 1] = GG[0];
   __shared__ float R[RP][RP + 1];
-  __shared__ float Cs[32], Ss[32];
-  __shared__ int Ps[32], Qs[32];
+  __shared__ float WCs[4][32], WSs[4][32];
+  __shared__ int WPs[4][32], WQs[4][32];
   __shared__ float red[4];
   const int t = threadIdx.x, p = blockIdx.x;
   const float* src = partials + (size_t)p * nch * RP * RP;
-  for (int e = t; e < RP * RP; e += 256) {
-    float s = 0.0f;
-    for (int ch = 0; ch < nch; ++ch) s += src[(size_t)ch * RP * RP + e];
-    G[e >> 6][e & 63] = s;
-    R[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0f : 0.0f;
+  {
+    // sum the column-chunk partials: 16 independent loads in flight per chunk
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int ch = 0; ch < nch; ++ch) {
+      const float* pc = src + (size_t)ch * RP * RP + t;
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = pc[256 * i];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = t + 256 * i;
+      G[e >> 6][e & 63] = acc[i];
+      R[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0f : 0.0f;
+    }
   }
   __syncthreads();
   float mx = 0.0f;
@@ -204,43 +227,68 @@ __global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ part
   __syncthreads();
   if (t == 0) atomicMax(maxcos_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 
-  for (int step = 0; step < RP - 1; ++step) {
-    if (t < 32) {
-      int a = rr_elem(t, step), b = rr_elem(RP - 1 - t, step);
+  // thread -> four 2x2 blocks (k1, k2) of G and eight (row, pair) items of R.
+  // Every wave computes all 32 rotations of the step redundantly (lanes 0..31)
+  // into its own LDS slice, so a step needs ONE workgroup barrier (after the
+  // updates) instead of two.
+  const int k1 = t >> 3, k2b = (t & 7) * 4;
+  const int wv = t >> 6, lane = t & 63;
+  float* Cw = &WCs[wv][0]; float* Sw_ = &WSs[wv][0];
+  int* Pw = &WPs[wv][0]; int* Qw = &WQs[wv][0];
+  const int n_inner = cross_only ? RB : RP - 1;
+  for (int step = 0; step < n_inner; ++step) {
+    if (lane < 32) {
+      const int a = cross_only ? lane : rr_elem(lane, step);
+      const int b = cross_only ? RB + ((lane + step) & (RB - 1)) : rr_elem(RP - 1 - lane, step);
       const int pp = min(a, b), qq = max(a, b);
       const float app = G[pp][pp], aqq = G[qq][qq], apq = G[pp][qq];
       const float tau = aqq - app, g2 = apq + apq;
-      const float h = sqrtf(fmaf(tau, tau, g2 * g2));
-      const float den = fabsf(tau) + h;
-      float tt = (den > 0.0f) ? g2 / den : 0.0f;
-      tt = (tau < 0.0f) ? -tt : tt;
-      const float c = 1.0f / sqrtf(fmaf(tt, tt, 1.0f)), s = c * tt;
-      const bool sw = tau > 0.0f;
-      Cs[t] = sw ? s : c;
-      Ss[t] = sw ? -c : s;
-      Ps[t] = pp; Qs[t] = qq;
+      const float ta = fabsf(tau) + 1e-18f;   // all-zero (padding) rows: cos = 1, sin = 0
+      const float ih = __builtin_amdgcn_rsqf(fmaf(g2, g2, ta * ta));   // 1/h, h^2 = tau^2 + 4 apq^2
+      const float x = fmaf(0.5f * ta, ih, 0.5f);                       // cos^2 in [0.5, 1]
+      const float rx = __builtin_amdgcn_rsqf(x);
+      const float c0 = x * rx, s0 = (apq * ih) * rx;                   // cos, sin * sign(apq)
+      const bool sw = tau > 0.0f;                                      // de Rijk: larger diagonal to pp
+      // X[:,p] <- C x_p - S x_q ; X[:,q] <- S x_p + C x_q   (same convention as the tile kernels)
+      Cw[lane] = sw ? s0 : c0;
+      Sw_[lane] = sw ? -c0 : -s0;
+      Pw[lane] = pp; Qw[lane] = qq;
+    }
+    // wave-local hand-off of the rotation table (same wave wrote it): no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float (*Gn)[RP + 1] = GG[(step + 1) & 1];
+    // G <- J^T G J, one 2x2 block (rows of pair k1, columns of pair k2) at a time
+    {
+      const int p1 = Pw[k1], q1 = Qw[k1];
+      const float C1 = Cw[k1], S1 = Sw_[k1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k2 = k2b + j;
+        const int p2 = Pw[k2], q2 = Qw[k2];
+        const float C2 = Cw[k2], S2 = Sw_[k2];
+        const float gpp = G[p1][p2], gpq = G[p1][q2], gqp = G[q1][p2], gqq = G[q1][q2];
+        const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;   // row p1, columns rotated
+        const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;   // row q1
+        Gn[p1][p2] = C1 * a0 - S1 * b0; Gn[p1][q2] = C1 * a1 - S1 * b1;    // rows rotated
+        Gn[q1][p2] = S1 * a0 + C1 * b0; Gn[q1][q2] = S1 * a1 + C1 * b1;
+      }
+    }
+    // R <- R J
+    {
+      const int k = t & 31;
+      const int pp = Pw[k], qq = Qw[k];
+      const float C = Cw[k], S = Sw_[k];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = (t >> 5) + 8 * i;
+        const float rp = R[r][pp], rq = R[r][qq];
+        R[r][pp] = C * rp - S * rq; R[r][qq] = S * rp + C * rq;
+      }
     }
     __syncthreads();
-    // column rotations of G and R:  X[:, p], X[:, q] <- C x_p - S x_q,  S x_p + C x_q
-    for (int e = t; e < RP * 32; e += 256) {
-      const int k = e & 31, r = e >> 5;
-      const int pp = Ps[k], qq = Qs[k];
-      const float C = Cs[k], S = Ss[k];
-      const float gp = G[r][pp], gq = G[r][qq];
-      G[r][pp] = C * gp - S * gq; G[r][qq] = S * gp + C * gq;
-      const float rp = R[r][pp], rq = R[r][qq];
-      R[r][pp] = C * rp - S * rq; R[r][qq] = S * rp + C * rq;
-    }
-    __syncthreads();
-    // row rotations of G
-    for (int e = t; e < RP * 32; e += 256) {
-      const int k = e >> 6, c = e & 63;
-      const int pp = Ps[k], qq = Qs[k];
-      const float C = Cs[k], S = Ss[k];
-      const float gp = G[pp][c], gq = G[qq][c];
-      G[pp][c] = C * gp - S * gq; G[qq][c] = S * gp + C * gq;
-    }
-    __syncthreads();
+    G = Gn;
   }
   float* out = Rout + (size_t)p * RP * RP;
   for (int e = t; e < RP * RP; e += 256) out[e] = R[e >> 6][e & 63];
@@ -436,7 +484,8 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
     for (int s = 0; s < p.nsteps; ++s) {
       const int2* pr = w.pairs + (size_t)s * p.npairs;
       hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, pr, w.partials);
-      hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs), dim3(256), 0, ctx->stream, w.partials, p.nch, w.R, w.maxcos);
+      hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs), dim3(256), 0, ctx->stream, w.partials, p.nch, w.R, w.maxcos,
+                         s == 0 ? 0 : 1);
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (ncols + 63) / 64), dim3(256), 0, ctx->stream, w.aug, p.ld, ncols, pr, w.R);
     }
     WM_HIP(hipGetLastError());

@@ -48,7 +48,7 @@ def test_fullframe_watermark_svd_and_extract(gpu_ctx, H, W):
     # extract with the ORACLE's meta (sign/cluster ambiguity of singular vectors cancels there)
     w = gpu_ctx.ref_extract(ref["stego"], ref["Sc"], ref["Uw"], ref["Vwt"], alpha, ref["K"])
     wo = o.extract_plane(ref["stego"].astype(np.float32), ref["Sc"], ref["Uw"], ref["Vwt"], alpha, 0.6, H, W, None)
-    assert np.abs(w - wo).max() < 5e-2 * max(1.0, np.abs(wo).max() / 255)
+    assert np.abs(w - wo).max() < 2e-3 * np.abs(wo).max()      # (S_cw - Sc) / alpha amplifies 1e-6 * sigma_1
     # and a full GPU round trip: GPU meta -> GPU extract correlates with the scrambled watermark
     st, sc, _ = gpu_ctx.ref_embed(host, S, alpha, ref["K"])
     w2 = gpu_ctx.ref_extract(st, sc, U, Vt, alpha, ref["K"])
