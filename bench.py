@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--alpha", type=float, default=0.15)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -90,11 +93,16 @@ def main():
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     api = importlib.import_module(PKG + ".hostapi")
     shard = importlib.import_module(PKG + ".sharding")
@@ -158,11 +166,13 @@ def main():
         value = world * F * a.steps / dt
         alg_bytes = 3.0 * H * W * F                                  # 3 B per pixel per plane
         achieved = alg_bytes / (embed_ms_avg * 1e-3) / 1e9
-        traffic = None
+        traffic = None    # HBM bytes per embed launch from the committed PMC passes (profiles/), scaled by frames
         pmc = os.path.join(ROOT, "profiles", "pmc_embed_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch_at_bench_shape")
+                j = json.load(open(pmc))
+                if (j.get("H"), j.get("W")) == (H, W):
+                    traffic = j["hbm_bytes_per_launch_at_bench_shape"] * F / j["frames_per_launch"]
             except Exception:
                 traffic = None
         out = {
