@@ -73,6 +73,18 @@ SIGNATURES = {
     "wm_ref_svd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_detect_u8": [_vp, _vp, _vp, _vp, C.POINTER(C.c_double), _i, _i, _i, _f],
+    "wm_bgr_to_ycrcb_u8_dev": [_vp, _vp, _vp, _sz],
+    "wm_ycrcb_to_bgr_u8_dev": [_vp, _vp, _vp, _sz],
+    "wm_bgr_to_gray_u8_dev": [_vp, _vp, _vp, _sz],
+    "wm_bgr_to_y_u8_dev": [_vp, _vp, _vp, _sz],
+    "wm_replace_y_u8_dev": [_vp, _vp, _vp, _vp, _sz],
+    "wm_sqdiff_u8_dev": [_vp, _vp, _vp, _sz, _vp],
+    "wm_ssim_dev": [_vp, _vp, _sz, _vp, _sz, _i, _i, _i, _vp],
+    "wm_normalize_u8_dev": [_vp, _vp, _sz, _i, _vp],
+    "wm_color_u8": [_vp, _i, _vp, _vp, _vp, _vp, _sz],
+    "wm_psnr_u8": [_vp, _vp, _vp, _sz, C.POINTER(C.c_double)],
+    "wm_ssim": [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_double)],
+    "wm_normalize_u8": [_vp, _vp, _sz, _i, _vp],
 }
 
 
@@ -396,3 +408,54 @@ class Context:
         self._call("wm_ref_detect_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
                    C.byref(score), H, W, W, float(alpha))
         return score.value
+
+    # ---- pixel-side kernels (colour, PSNR, SSIM, normalise) ----------------------
+    _COLOR_OPS = {"bgr2ycrcb": 0, "ycrcb2bgr": 1, "bgr2gray": 2, "bgr2y": 3, "replace_y": 4}
+
+    def color(self, op: str, img: np.ndarray, plane: Optional[np.ndarray] = None) -> np.ndarray:
+        """img: uint8 [H, W, 3]; returns [H, W, 3] (ops 0, 1, 4) or the [H, W] plane (ops 2, 3)."""
+        code = self._COLOR_OPS[op]
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("img must be uint8 [H, W, 3]")
+        img = np.ascontiguousarray(img)
+        H, W = img.shape[:2]
+        if code in (2, 3):
+            out = np.empty((H, W), np.uint8)
+            self._call("wm_color_u8", code, _vp(img.ctypes.data), None, None, _vp(out.ctypes.data), H * W)
+            return out
+        out = np.empty_like(img)
+        pin = None
+        if code == 4:
+            plane = np.ascontiguousarray(plane, dtype=np.uint8)
+            if plane.shape != (H, W):
+                raise ValueError("plane must be [H, W]")
+            pin = _vp(plane.ctypes.data)
+        self._call("wm_color_u8", code, _vp(img.ctypes.data), pin, _vp(out.ctypes.data), None, H * W)
+        return out
+
+    def psnr(self, a: np.ndarray, b: np.ndarray) -> float:
+        a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+        if a.shape != b.shape:
+            raise ValueError("shape mismatch")
+        v = C.c_double(0.0)
+        self._call("wm_psnr_u8", _vp(a.ctypes.data), _vp(b.ctypes.data), a.size, C.byref(v))
+        return v.value
+
+    def ssim(self, img1: np.ndarray, img2: np.ndarray) -> float:
+        """planes [H, W], each uint8 or float32"""
+        def prep(x):
+            if x.dtype == np.uint8:
+                return np.ascontiguousarray(x), 0
+            return np.ascontiguousarray(x, dtype=np.float32), 1
+        x, k1 = prep(img1); y, k2 = prep(img2)
+        if x.shape != y.shape or x.ndim != 2:
+            raise ValueError("planes must be [H, W] of equal shape")
+        v = C.c_double(0.0)
+        self._call("wm_ssim", _vp(x.ctypes.data), _vp(y.ctypes.data), x.shape[0], x.shape[1], k1 | (k2 << 1), C.byref(v))
+        return v.value
+
+    def normalize_u8(self, x: np.ndarray, normalize: bool = True) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(x.shape, np.uint8)
+        self._call("wm_normalize_u8", _vp(x.ctypes.data), x.size, 1 if normalize else 0, _vp(out.ctypes.data))
+        return out

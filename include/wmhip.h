@@ -188,6 +188,36 @@ int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, c
 int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
                      double* score, int H, int W, int row_stride, float alpha);
 
+/* ==========================================================================
+ * Pixel-side kernels either side of the hot path.  Colour
+ * conversion is OpenCV's 8-bit fixed point, bit-exact integer work; images
+ * are contiguous interleaved 3-channel uint8 (n_px pixels), planes contiguous.
+ * *_dev: device pointers (16-byte aligned), asynchronous on the context stream.
+ * ========================================================================== */
+/* cv2.cvtColor(BGR2YCrCb) / (YCrCb2BGR) / (BGR2GRAY)          single:22, 30, 45, 170 */
+int wm_bgr_to_ycrcb_u8_dev(wm_ctx* ctx, const uint8_t* bgr, uint8_t* ycrcb, size_t n_px);
+int wm_ycrcb_to_bgr_u8_dev(wm_ctx* ctx, const uint8_t* ycrcb, uint8_t* bgr, size_t n_px);
+int wm_bgr_to_gray_u8_dev(wm_ctx* ctx, const uint8_t* bgr, uint8_t* gray, size_t n_px);
+/* _to_Y (single:21-24): the Y plane of BGR2YCrCb only */
+int wm_bgr_to_y_u8_dev(wm_ctx* ctx, const uint8_t* bgr, uint8_t* y, size_t n_px);
+/* _from_Y (single:26-30): YCrCb of `bgr` with Y replaced by y_new, back to BGR */
+int wm_replace_y_u8_dev(wm_ctx* ctx, const uint8_t* bgr, const uint8_t* y_new, uint8_t* bgr_out, size_t n_px);
+/* sum of squared differences of two uint8 buffers (exact integer; psnr of single:38-42 follows) */
+int wm_sqdiff_u8_dev(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, unsigned long long* ssd_dev);
+/* mean SSIM (single:44-57: 11x11 sigma 1.5 Gaussian, reflect-101 border) of two planes;
+ * strides in elements; kind bit0 / bit1: img1 / img2 is float32 instead of uint8 */
+int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2, size_t stride2,
+                int H, int W, int kind, double* ssim_dev);
+/* uint8(clip(cv2.normalize(x, 0, 255, NORM_MINMAX), 0, 255))  (single:221-222); do_norm=0: clip only */
+int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint8_t* out);
+/* host-pointer conveniences; op: 0 BGR->YCrCb, 1 YCrCb->BGR, 2 BGR->gray plane, 3 BGR->Y plane,
+ * 4 replace Y (plane_in) and return BGR */
+int wm_color_u8(wm_ctx* ctx, int op, const uint8_t* in3, const uint8_t* plane_in, uint8_t* out3,
+                uint8_t* plane_out, size_t n_px);
+int wm_psnr_u8(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double* psnr_out);
+int wm_ssim(wm_ctx* ctx, const void* img1, const void* img2, int H, int W, int kind, double* ssim_out);
+int wm_normalize_u8(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif
