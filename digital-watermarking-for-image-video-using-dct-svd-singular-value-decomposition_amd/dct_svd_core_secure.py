@@ -92,19 +92,18 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
                                       meta["UWb"], meta["UWg"], meta["UWr"],
                                       meta["VWbt"], meta["VWgt"], meta["VWrt"]])   # single:152-156
         meta["digest"] = np.frombuffer(digest, dtype=np.uint8)
-        return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego), ssim=hg.ssim(cover, stego))  # single:167
-    ycc = hg.bgr_to_ycrcb(cover)                                           # single:169
-    Y = np.ascontiguousarray(ycc[..., 0])
-    wy_s = hg.permute(hg.bgr_to_gray(wm).astype(np.float32), idx)          # single:170-171
+        return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
+                    ssim=ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego)))   # single:167
+    Y = ctx.color("bgr2y", cover)                                          # single:169  (_to_Y)
+    wy_s = hg.permute(ctx.color("bgr2gray", wm).astype(np.float32), idx)   # single:170-171
     Uw, Sw, Vwt = ctx.svd_tiles(wy_s)                                      # single:173
     stegoY, Sc, Yw = ctx.embed_tiles(Y, Sw, alpha, K, want_yw=True)        # single:172-177
-    out = ycc.copy(); out[..., 0] = stegoY                                 # single:27-29
-    stego = hg.ycrcb_to_bgr(out)                                           # single:30
+    stego = ctx.color("replace_y", cover, stegoY)                          # single:26-30 (_from_Y)
     digest = hg.hmac_digest(key, [Sc, Uw, Vwt])                            # single:182
     meta = dict(mode="gray", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw, **common,
                 digest=np.frombuffer(digest, dtype=np.uint8))              # single:183-189
-    return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego),
-                ssim=hg.ssim(hg.bgr_to_gray(cover), Yw))                   # single:190
+    return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
+                ssim=ctx.ssim(ctx.color("bgr2gray", cover), Yw))           # single:190
 
 
 def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac, k_floor) -> dict:
@@ -130,19 +129,18 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
         digest = hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"], meta["UWb"], meta["UWg"], meta["UWr"],
                                       meta["VWbt"], meta["VWgt"], meta["VWrt"]])
         meta["digest"] = np.frombuffer(digest, dtype=np.uint8)
-        return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego), ssim=hg.ssim(cover, stego))
-    ycc = hg.bgr_to_ycrcb(cover)
-    Y = np.ascontiguousarray(ycc[..., 0])
-    wy_s = hg.permute(hg.bgr_to_gray(wm).astype(np.float32), idx)
+        return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
+                    ssim=ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego)))
+    Y = ctx.color("bgr2y", cover)
+    wy_s = hg.permute(ctx.color("bgr2gray", wm).astype(np.float32), idx)
     Uw, Sw, Vwt = ctx.ref_svd(wy_s, apply_dct=True)                        # single:173
     stegoY, Sc, Yw = ctx.ref_embed(Y, Sw, alpha, K, want_yw=True)          # single:172-177
-    out = ycc.copy(); out[..., 0] = stegoY
-    stego = hg.ycrcb_to_bgr(out)
+    stego = ctx.color("replace_y", cover, stegoY)
     digest = hg.hmac_digest(key, [Sc, Uw, Vwt])
     meta = dict(mode="gray", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw, **common,
                 digest=np.frombuffer(digest, dtype=np.uint8))
-    return dict(stego=stego, meta=meta, psnr=hg.psnr(cover, stego),
-                ssim=hg.ssim(hg.bgr_to_gray(cover), Yw))
+    return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
+                ssim=ctx.ssim(ctx.color("bgr2gray", cover), Yw))
 
 
 def _meta_tile(meta) -> Optional[int]:
@@ -181,12 +179,10 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
         return _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, W, idx, normalize)
     K = _k_of(TILE, kfrac, k_floor)
     if mode == "gray":
-        Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])           # single:204
+        Y = ctx.color("bgr2y", stego)                                      # single:204
         wy_s = ctx.extract_tiles(Y, meta["Sc"], meta["Uw"], meta["Vwt"], alpha, K)   # single:205-218
         wy = hg.unpermute(wy_s, idx)                                       # single:220
-        if normalize:
-            wy = hg.normalize_minmax(wy)                                   # single:221
-        return np.clip(wy, 0, 255).astype(np.uint8)                        # single:222
+        return ctx.normalize_u8(wy, normalize)                             # single:221-222
     planes = np.ascontiguousarray(np.moveaxis(stego, -1, 0))               # single:232
     Sc = np.stack([meta["S" + n] for n in "bgr"])
     U = np.stack([meta["UW" + n] for n in "bgr"])
@@ -195,9 +191,7 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
     outs = []
     for ch in range(3):
         w = hg.unpermute(ws[ch], idx)                                      # single:266-267
-        if normalize:
-            w = hg.normalize_minmax(w)                                     # single:269-271
-        outs.append(np.clip(w, 0, 255).astype(np.uint8))                   # single:272-274
+        outs.append(ctx.normalize_u8(w, normalize))                        # single:269-274
     return np.stack(outs, axis=-1)
 
 
@@ -206,22 +200,16 @@ def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, 
         L = min(len(Sc), min(H, W), S_len_u, S_len_v)                      # single:210
         return _k_of(L, kfrac, k_floor)
     if mode == "gray":
-        Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])
+        Y = ctx.color("bgr2y", stego)
         Uw, Vwt = meta["Uw"], meta["Vwt"]
         wy_s = ctx.ref_extract(Y, meta["Sc"], Uw, Vwt, alpha, k_for(meta["Sc"], Uw.shape[0], Vwt.shape[0]))
-        wy = hg.unpermute(wy_s, idx)
-        if normalize:
-            wy = hg.normalize_minmax(wy)
-        return np.clip(wy, 0, 255).astype(np.uint8)
+        return ctx.normalize_u8(hg.unpermute(wy_s, idx), normalize)
     outs = []
     for ch, n in enumerate("bgr"):
         U, Vt, Sc = meta["UW" + n], meta["VW" + n + "t"], meta["S" + n]
         w_s = ctx.ref_extract(np.ascontiguousarray(stego[..., ch]), Sc, U, Vt, alpha,
                               k_for(Sc, U.shape[0], Vt.shape[0]))
-        w = hg.unpermute(w_s, idx)
-        if normalize:
-            w = hg.normalize_minmax(w)
-        outs.append(np.clip(w, 0, 255).astype(np.uint8))
+        outs.append(ctx.normalize_u8(hg.unpermute(w_s, idx), normalize))
     return np.stack(outs, axis=-1)
 
 
@@ -231,7 +219,7 @@ def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0)
     ctx = _ctx(device)
     if tile is None:
         if mode == "gray":
-            Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])
+            Y = ctx.color("bgr2y", stego)
             score = ctx.ref_detect(Y, meta["Sc"], meta["Sw"], alpha)       # single:297-301
             return bool(score >= thresh), float(score)
         nc = [ctx.ref_detect(np.ascontiguousarray(stego[..., ch]), meta["S" + n], meta["SW" + n], alpha)
@@ -239,7 +227,7 @@ def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0)
         score = float((nc[0] + nc[1] + nc[2]) / 3.0)
         return bool(score >= thresh), score
     if mode == "gray":
-        Y = np.ascontiguousarray(hg.bgr_to_ycrcb(stego)[..., 0])           # single:296
+        Y = ctx.color("bgr2y", stego)                                      # single:296
         score = float(ctx.detect_tiles(Y, meta["Sc"], meta["Sw"], alpha)[0])   # single:297-301
         return bool(score >= thresh), score                                # single:302
     planes = np.ascontiguousarray(np.moveaxis(stego, -1, 0))               # single:303
