@@ -131,3 +131,34 @@ def test_rank_deficient_tiles_on_gpu(gpu_ctx):
     I = np.eye(8, dtype=np.float32)
     assert np.abs(np.matmul(U.swapaxes(-1, -2), U) - I).max() < 1e-5
     assert np.abs(np.matmul(Vt, Vt.swapaxes(-1, -2)) - I).max() < 1e-5
+
+
+def test_unaligned_and_strided_planes(gpu_ctx, hostapi):
+    """Byte-wise kernel variants: row stride / base address not multiples of 8,
+    planes embedded in a larger buffer (row_stride > W, plane_stride > H*row_stride)."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    big = rng.integers(0, 256, (3, 70, 101), dtype=np.uint8)
+    view = big[:, 3:3 + 48, 5:5 + 72]                      # base offset 5 (odd), row stride 101, plane stride 7070
+    dense = np.ascontiguousarray(view)
+    s_strided = gpu_ctx.sigma_tiles(view)
+    s_dense = gpu_ctx.sigma_tiles(dense)
+    assert np.array_equal(s_strided, s_dense)
+    assert _rel_sigma(s_dense[1], o.stego_sigma(dense[1].astype(np.float32), 8)) < SIGMA_RTOL
+    # embed through the raw ABI with strided input AND strided output; bytes outside the planes survive
+    wys = rng.integers(0, 256, (48, 72)).astype(np.float32)
+    Uo, So, Vto = o.watermark_decompose(wys, 8)
+    sw = np.ascontiguousarray(So.reshape(-1, 8))
+    out_big = np.full_like(big, 7)
+    sc = np.empty((3, 6 * 9, 8), np.float32)
+    vp = lambda a, off=0: C.c_void_p(a.ctypes.data + off)
+    off = 3 * 101 + 5
+    gpu_ctx._call("wm_embed_tiles_u8", vp(big, off), vp(sw), vp(out_big, off), vp(sc), None,
+                  3, 48, 72, 101, 70 * 101, 0, 0.15, 8)
+    for p in range(3):
+        ref = o.embed_plane(dense[p].astype(np.float32), wys, 0.15, 0.6, 8, wm_svd=(Uo, So, Vto))
+        got = out_big[p, 3:51, 5:77]
+        assert np.abs(got.astype(int) - ref["stego"].astype(int)).max() <= 1
+        assert _rel_sigma(sc[p], ref["Sc"]) < SIGMA_RTOL
+    mask = np.ones_like(big, bool); mask[:, 3:51, 5:77] = False
+    assert np.all(out_big[mask] == 7)

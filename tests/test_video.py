@@ -1,0 +1,85 @@
+"""Video frame loop: Y4M container (CPU) and the batched embed / averaged
+extract / detect over frames (GPU)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import PKG_NAME
+from oracle import wm_oracle as o
+
+
+def _video(tmp_path, n=9, H=64, W=96, seed=3):
+    rng = np.random.default_rng(seed)
+    ys = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    chroma = rng.integers(0, 256, (n, 2 * (H // 2) * (W // 2)), dtype=np.uint8)
+    v = importlib.import_module(PKG_NAME + ".video")
+    p = str(tmp_path / "in.y4m")
+    v.write_y4m(p, ys, chroma)
+    return v, p, ys, chroma
+
+
+def test_y4m_roundtrip(tmp_path):
+    v, p, ys, chroma = _video(tmp_path)
+    vid = v.Y4M(p)
+    assert (vid.W, vid.H, vid.chroma) == (96, 64, "420")
+    got = [(y.copy(), c.copy()) for _, y, c in vid]
+    vid.close()
+    assert len(got) == 9
+    for i, (y, c) in enumerate(got):
+        assert np.array_equal(y, ys[i]) and np.array_equal(c, chroma[i])
+    mono = str(tmp_path / "m.y4m")
+    v.write_y4m(mono, ys[:2])
+    vm = v.Y4M(mono); frames = list(vm); vm.close()
+    assert len(frames) == 2 and frames[0][2].size == 0
+    open(str(tmp_path / "bad.y4m"), "wb").write(b"RIFFxxxx")
+    with pytest.raises(ValueError):
+        v.Y4M(str(tmp_path / "bad.y4m"))
+    sh = importlib.import_module(PKG_NAME + ".sharding")
+    assert [sh.frame_range(r, 4, 9) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 9)]
+
+
+@pytest.mark.gpu
+def test_video_embed_extract_detect(tmp_path, gpu_ctx):
+    v, p, ys, chroma = _video(tmp_path)
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    wm = np.random.default_rng(5).integers(0, 256, (16, 24, 3), dtype=np.uint8)
+    wp = str(tmp_path / "wm.png"); assert hg.write_png(wp, wm)
+    outp, meta, ps = v.embed_watermark_video(p, wp, str(tmp_path / "out.y4m"), str(tmp_path / "vm.npz"),
+                                             alpha=0.15, frame_interval=2, password="pw", nonce=bytes(8), batch=2)
+    assert 15 < ps < 60
+    data = np.load(meta, allow_pickle=False)
+    assert data["Sc"].shape == (5, 8, 12, 8) and int(data["frame_interval"]) == 2 and int(data["n_frames"]) == 9
+    vid = v.Y4M(outp); got = [(y.copy(), c.copy()) for _, y, c in vid]; vid.close()
+    assert len(got) == 9
+    # oracle: same watermark preparation, per-frame tile-mode embed with the shared decomposition
+    key = o.derive_key("pw", bytes(8)); idx = o.permutation(64, 96, o.rng_from_key(key))
+    wy_s = o.permute(o.bgr_to_gray(o.resize_area(wm, 96, 64)).astype(np.float32), idx)
+    wm_svd = o.watermark_decompose(wy_s, 8)
+    for i, (y, c) in enumerate(got):
+        assert np.array_equal(c, chroma[i])                               # chroma untouched
+        if i % 2:
+            assert np.array_equal(y, ys[i])                               # unmarked frames untouched
+        else:
+            ref = o.embed_plane(ys[i].astype(np.float32), wy_s, 0.15, 0.6, 8, wm_svd=wm_svd)
+            assert np.abs(y.astype(int) - ref["stego"].astype(int)).max() <= 1
+            assert np.max(np.abs(data["Sc"][i // 2] - ref["Sc"]) / ref["Sc"][..., :1]) < 1e-4
+    ok, mean, scores = v.detect_watermark_video(outp, meta)
+    assert ok and mean > 0.9 and scores.shape == (5,)
+    ok0, mean0, _ = v.detect_watermark_video(p, meta)                      # the unmarked video
+    assert not ok0
+    wout = v.extract_watermark_video(outp, meta, str(tmp_path / "w.png"), password="pw")
+    ex = hg.read_image_bgr(wout)[..., 0]
+    want = o.bgr_to_gray(o.resize_area(wm, 96, 64))
+    assert np.corrcoef(ex.ravel().astype(float), want.ravel().astype(float))[0, 1] > 0.8
+    with pytest.raises(ValueError, match="Sai mật khẩu"):
+        v.extract_watermark_video(outp, meta, str(tmp_path / "x.png"), password="nope")
+    with pytest.raises(ValueError):
+        v.embed_watermark_video(p, wp, outp, meta, password="")
+    # array-level sharded embed: two ranks' shares tile the batch and equal the unsharded result
+    st_all, sc_all = v.embed_frames(gpu_ctx, ys, wm_svd[1], 0.15)
+    parts = [v.embed_frames_sharded(gpu_ctx, ys, wm_svd[1], 0.15, rank=r, world_size=2) for r in range(2)]
+    assert parts[0][0] == (0, 4) and parts[1][0] == (4, 9)
+    assert np.array_equal(np.concatenate([parts[0][1], parts[1][1]]), st_all)
+    assert np.array_equal(np.concatenate([parts[0][2], parts[1][2]]), sc_all)
