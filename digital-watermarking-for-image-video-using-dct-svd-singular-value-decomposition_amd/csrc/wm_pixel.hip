@@ -171,35 +171,54 @@ __global__ __launch_bounds__(256) void k_ssim(const TA* __restrict__ img1, const
     B[ly][lx] = (float)img2[(size_t)gy * s2 + gx];
   }
   __syncthreads();
-  for (int e = t; e < SW_ * ST; e += 256) {
-    const int ly = e / ST, lx = e % ST;
-    float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+  // horizontal pass: 42 rows x 4 strips of 8 outputs; one strip per work item, 18 loads per operand
+  for (int e = t; e < SW_ * (ST / 8); e += 256) {
+    const int ly = e / (ST / 8), lx0 = (e % (ST / 8)) * 8;
+    float av[18], bv[18];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float a = A[ly][lx + k], b = B[ly][lx + k], w = taps.w[k];
-      sx = fmaf(w, a, sx); sy = fmaf(w, b, sy);
-      sxx = fmaf(w, a * a, sxx); syy = fmaf(w, b * b, syy); sxy = fmaf(w, a * b, sxy);
+    for (int k = 0; k < 18; ++k) { av[k] = A[ly][lx0 + k]; bv[k] = B[ly][lx0 + k]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float a = av[j + k], b = bv[j + k], w = taps.w[k];
+        sx = fmaf(w, a, sx); sy = fmaf(w, b, sy);
+        sxx = fmaf(w, a * a, sxx); syy = fmaf(w, b * b, syy); sxy = fmaf(w, a * b, sxy);
+      }
+      Hm[0][ly][lx0 + j] = sx; Hm[1][ly][lx0 + j] = sy; Hm[2][ly][lx0 + j] = sxx;
+      Hm[3][ly][lx0 + j] = syy; Hm[4][ly][lx0 + j] = sxy;
     }
-    Hm[0][ly][lx] = sx; Hm[1][ly][lx] = sy; Hm[2][ly][lx] = sxx; Hm[3][ly][lx] = syy; Hm[4][ly][lx] = sxy;
   }
   __syncthreads();
+  // vertical pass + SSIM map: 32 columns x 4 strips of 8 rows; thread = (column, strip)
   double acc = 0.0;
   const float C1 = (0.01f * 255) * (0.01f * 255), C2 = (0.03f * 255) * (0.03f * 255);
-  for (int e = t; e < ST * ST; e += 256) {
-    const int ly = e / ST, lx = e % ST;
-    if (y0 + ly >= H || x0 + lx >= W) continue;
-    float m[5] = {0, 0, 0, 0, 0};
+  if (t < ST * (ST / 8)) {
+    const int lx = t % ST, ly0 = (t / ST) * 8;
+    float m[5][8];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = taps.w[k];
+    for (int q = 0; q < 5; ++q) {
+      float col[18];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) m[q] = fmaf(w, Hm[q][ly + k][lx], m[q]);
+      for (int k = 0; k < 18; ++k) col[k] = Hm[q][ly0 + k][lx];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) s = fmaf(taps.w[k], col[j + k], s);
+        m[q][j] = s;
+      }
     }
-    const float mu1 = m[0], mu2 = m[1];
-    const float s1q = m[2] - mu1 * mu1, s2q = m[3] - mu2 * mu2, s12 = m[4] - mu1 * mu2;
-    const float num = (2 * mu1 * mu2 + C1) * (2 * s12 + C2);
-    const float den = (mu1 * mu1 + mu2 * mu2 + C1) * (s1q + s2q + C2) + 1e-12f;
-    acc += (double)(num / den);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (y0 + ly0 + j >= H || x0 + lx >= W) continue;
+      const float mu1 = m[0][j], mu2 = m[1][j];
+      const float s1q = m[2][j] - mu1 * mu1, s2q = m[3][j] - mu2 * mu2, s12 = m[4][j] - mu1 * mu2;
+      const float num = (2 * mu1 * mu2 + C1) * (2 * s12 + C2);
+      const float den = (mu1 * mu1 + mu2 * mu2 + C1) * (s1q + s2q + C2) + 1e-12f;
+      acc += (double)(num / den);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -348,10 +367,9 @@ int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint
   if (n == 0) return WM_OK;
   if (!x || !out) return set_err(WM_ERR_BADARG, "NULL argument");
   WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, 64, "minmax"));
-  unsigned* mm = (unsigned*)ctx->partials;
-  const unsigned init[2] = {0xffffffffu, 0u};
-  WM_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  WM_HIP(hipStreamSynchronize(ctx->stream));      // init is a stack local
+  unsigned* mm = (unsigned*)ctx->partials;       // {min, max} in order-preserving uint form
+  WM_HIP(hipMemsetAsync(mm, 0xff, sizeof(unsigned), ctx->stream));
+  WM_HIP(hipMemsetAsync(mm + 1, 0x00, sizeof(unsigned), ctx->stream));
   if (do_norm) hipLaunchKernelGGL(k_minmax, dim3(grid_for(n)), dim3(256), 0, ctx->stream, x, n, mm);
   hipLaunchKernelGGL(k_normalize_u8, dim3(grid_for(n)), dim3(256), 0, ctx->stream, x, n, mm, do_norm, out);
   WM_HIP(hipGetLastError());

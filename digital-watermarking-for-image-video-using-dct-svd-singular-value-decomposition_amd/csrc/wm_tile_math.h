@@ -254,13 +254,14 @@ constexpr float SIGMA_RATIO_MIN2 = 1e-10f;   // (s_8 / s_1)^2 below this -> lite
 
 // one Jacobi rotation of columns p,q (no V).  c0 = cos, s0 = sin*sign(g) from
 // two v_rsq_f32:  cos^2 = (1 + |tau|/h)/2,  sin = g / (h cos),  h^2 = tau^2+4g^2.
+template <bool CHECK>
 WM_HD void jacobi_rot_pk(v2f (&a)[4][8], float (&n2)[8], const int p, const int q, bool& notconv) {
   v2f gv = a[0][p] * a[0][q];
 #pragma unroll
   for (int rp = 1; rp < 4; ++rp) gv = fma2(a[rp][p], a[rp][q], gv);
   const float g = gv[0] + gv[1];
   const float al = n2[p], be = n2[q];
-  notconv = notconv || (g * g > JAC_CONV2 * (al * be));
+  if (CHECK) notconv = notconv || (g * g > JAC_CONV2 * (al * be));
   const float tau = be - al;
   const float ta = fabsf(tau) + 1e-18f;          // keeps 0/0 out: g == 0 -> cos = 1 exactly
   const float g2 = g + g;
@@ -295,16 +296,29 @@ WM_HD void col_norms2_pk(const v2f (&a)[4][8], float (&n2)[8]) {
 
 // B = X V with orthogonal columns sorted by norm; n2 = |b_i|^2.  Returns the
 // sweep count (negative: bound hit).
+template <bool CHECK>
+WM_HD void jacobi_sweep_pk(v2f (&a)[4][8], float (&n2)[8], bool& notconv) {
+#pragma unroll
+  for (int p = 0; p < 7; ++p)
+#pragma unroll
+    for (int q = p + 1; q < 8; ++q) jacobi_rot_pk<CHECK>(a, n2, p, q, notconv);
+}
+
 WM_HD int jacobi_cols_pk(v2f (&a)[4][8], float (&n2)[8]) {
-  int sweep = 0;
+  // Sweeps 1 and 2 carry no convergence test (a sweep can only be the last one if
+  // it tested every pair, so these two are never last; on image tiles the earliest
+  // last sweep is the 4th).  Column norms are recomputed before odd sweeps and
+  // tracked through the even ones.
+  bool notconv = false;
+  col_norms2_pk(a, n2);
+  jacobi_sweep_pk<false>(a, n2, notconv);
+  jacobi_sweep_pk<false>(a, n2, notconv);
+  int sweep = 2;
   bool more = true;
   while (more && sweep < JAC_MAX_SWEEPS) {
-    col_norms2_pk(a, n2);
-    bool notconv = false;
-#pragma unroll
-    for (int p = 0; p < 7; ++p)
-#pragma unroll
-      for (int q = p + 1; q < 8; ++q) jacobi_rot_pk(a, n2, p, q, notconv);
+    if ((sweep & 1) == 0) col_norms2_pk(a, n2);
+    notconv = false;
+    jacobi_sweep_pk<true>(a, n2, notconv);
     ++sweep;
     more = wave_any(notconv);
   }

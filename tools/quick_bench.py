@@ -53,6 +53,18 @@ def main():
     ctx.embed_tiles_u8_dev(d_host, d_S, d_stego, d_sc, None, F, H, W, W, H * W, 0, a.alpha, 8)
     timed("extract", lambda: ctx.extract_tiles_u8_dev(d_stego, d_sc, d_U, d_V, d_out, F, H, W, W, H * W, 0, a.alpha, 8), 10.5 * P * F)
     timed("detect", lambda: ctx.detect_tiles_u8_dev(d_stego, d_sc, d_S, d_scores, F, H, W, W, H * W, 0, a.alpha), 2.0 * P * F)
+    # pixel-side streaming kernels (device-resident): algorithmic bytes / HIP-event time
+    n_px = F * H * W
+    d_bgr = ctx.malloc(n_px * 3); d_bgr2 = ctx.malloc(n_px * 3); d_y = ctx.malloc(n_px)
+    ctx.memset(d_bgr, 0x5a, n_px * 3)
+    d_ssd = ctx.malloc(64); d_ss = ctx.malloc(64)
+    timed("bgr2ycc", lambda: ctx._call("wm_bgr_to_ycrcb_u8_dev", d_bgr, d_bgr2, n_px), 6.0 * n_px)
+    timed("bgr2y", lambda: ctx._call("wm_bgr_to_y_u8_dev", d_bgr, d_y, n_px), 4.0 * n_px)
+    timed("replace_y", lambda: ctx._call("wm_replace_y_u8_dev", d_bgr, d_y, d_bgr2, n_px), 7.0 * n_px)
+    timed("sqdiff", lambda: ctx._call("wm_sqdiff_u8_dev", d_bgr, d_bgr2, n_px * 3, d_ssd), 6.0 * n_px)
+    timed("ssim", lambda: [ctx._call("wm_ssim_dev", d_host + i * H * W, W, d_stego + i * H * W, W, H, W, 0, d_ss)
+                           for i in range(F)], 2.0 * n_px)
+    timed("norm_u8", lambda: ctx._call("wm_normalize_u8_dev", d_out, n_px, 1, d_y), 9.0 * n_px)
     ctx.check_status()
     sc = np.zeros(F, np.float64); ctx.d2h(sc, d_scores)
     print("detect scores", sc[:4])
