@@ -111,9 +111,12 @@ int sgemm(wm_ctx* ctx, bool ta, bool tb, int M, int N, int K, float alpha, const
 // i >= L are zero padding; the identity block is Lp x Lp.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void k_rf_load(const T* __restrict__ src, const size_t src_stride, const int transpose,
-                          float* __restrict__ aug, const int ld, const int L, const int Lp, const int M) {
+__global__ void k_rf_load(const T* __restrict__ src, const size_t src_stride, const size_t src_plane_stride,
+                          const int transpose, float* __restrict__ aug, const size_t aug_plane_stride,
+                          const int ld, const int L, const int Lp, const int M) {
   const int i = blockIdx.y;
+  src += (size_t)blockIdx.z * src_plane_stride;
+  aug += (size_t)blockIdx.z * aug_plane_stride;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M + Lp; j += gridDim.x * blockDim.x) {
     float v;
     if (j < M) v = (i < L) ? (float)(transpose ? src[(size_t)j * src_stride + i] : src[(size_t)i * src_stride + j]) : 0.0f;
@@ -126,11 +129,14 @@ __global__ void k_rf_load(const T* __restrict__ src, const size_t src_stride, co
 // Gram partials: for pair p = (I, J) and column chunk ch,
 //   partial[p][ch][r][c] = sum_{k in chunk} X[r][k] X[c][k],  X = rows of blocks I,J
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, const int ld, const int M,
-                                                const int2* __restrict__ pairs, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, const size_t aug_plane_stride,
+                                                const int ld, const int M, const int2* __restrict__ pairs,
+                                                float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float Xt[32][68];   // [k][row]
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const int p = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
+  aug += (size_t)blockIdx.z * aug_plane_stride;
+  partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
   const int2 pr = pairs[p];
   const int c_begin = ch * GRAM_CC, c_end = min(M, c_begin + GRAM_CC);
   float acc[4][4] = {};
@@ -191,6 +197,9 @@ __global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ part
   __shared__ int WPs[4][32], WQs[4][32];
   __shared__ float red[4];
   const int t = threadIdx.x, p = blockIdx.x;
+  partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
+  Rout += (size_t)blockIdx.z * gridDim.x * RP * RP;
+  maxcos_bits += blockIdx.z;
   const float* src = partials + (size_t)p * nch * RP * RP;
   {
     // sum the column-chunk partials: 16 independent loads in flight per chunk
@@ -297,12 +306,15 @@ __global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ part
 // ---------------------------------------------------------------------------
 // Aug rows of the pair <- R^T x rows, one 64-column tile per workgroup.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rf_apply(float* __restrict__ aug, const int ld, const int ncols,
-                                                 const int2* __restrict__ pairs, const float* __restrict__ Rall) {
+__global__ __launch_bounds__(256) void k_rf_apply(float* __restrict__ aug, const size_t aug_plane_stride,
+                                                 const int ld, const int ncols, const int2* __restrict__ pairs,
+                                                 const float* __restrict__ Rall) {
   __shared__ __attribute__((aligned(16))) float Rs[RP][68];   // [k][i]
   __shared__ __attribute__((aligned(16))) float Xs[RP][68];   // [k][c]
   const int t = threadIdx.x, tc = t & 15, ti = t >> 4;
   const int p = blockIdx.x, c0 = blockIdx.y * 64;
+  aug += (size_t)blockIdx.z * aug_plane_stride;
+  Rall += (size_t)blockIdx.z * gridDim.x * RP * RP;
   const int2 pr = pairs[p];
   const float* Rp = Rall + (size_t)p * RP * RP;
 #pragma unroll
@@ -339,10 +351,14 @@ __global__ __launch_bounds__(256) void k_rf_apply(float* __restrict__ aug, const
 }
 
 // squared norms of the B part (first M columns) and the Qt part of every row
-__global__ __launch_bounds__(256) void k_rf_rownorms(const float* __restrict__ aug, const int ld, const int M,
-                                                    const int Lp, double* __restrict__ b2, double* __restrict__ q2) {
+__global__ __launch_bounds__(256) void k_rf_rownorms(const float* __restrict__ aug, const size_t aug_plane_stride,
+                                                    const int ld, const int M, const int Lq,
+                                                    double* __restrict__ b2, double* __restrict__ q2) {
   __shared__ double red[2][4];
   const int i = blockIdx.x, t = threadIdx.x;
+  const int Lp = Lq;
+  aug += (size_t)blockIdx.y * aug_plane_stride;
+  b2 += (size_t)blockIdx.y * gridDim.x; q2 += (size_t)blockIdx.y * gridDim.x;
   const float* row = aug + (size_t)i * ld;
   double sb = 0.0, sq = 0.0;
   for (int j = t; j < M; j += 256) sb += (double)row[j] * (double)row[j];
@@ -358,18 +374,23 @@ __global__ __launch_bounds__(256) void k_rf_rownorms(const float* __restrict__ a
 }
 
 // rows of the B part scaled in place:  B[i][:] *= d[i]
-__global__ void k_rf_scale_rows(float* __restrict__ aug, const int ld, const int M, const float* __restrict__ d) {
+__global__ void k_rf_scale_rows(float* __restrict__ aug, const size_t aug_plane_stride, const int ld,
+                                const int M, const float* __restrict__ d) {
   const int i = blockIdx.y;
-  const float s = d[i];
+  aug += (size_t)blockIdx.z * aug_plane_stride;
+  const float s = d[(size_t)blockIdx.z * gridDim.y + i];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x)
     aug[(size_t)i * ld + j] *= s;
 }
 
 // Yw (float, logical A layout L x M or its transpose) -> clip/truncate -> uint8 plane; optional float copy
-__global__ void k_rf_quant(const float* __restrict__ yw, const int ldy, const int transpose,
-                           uint8_t* __restrict__ dst, const size_t dst_stride, float* __restrict__ ywout,
-                           const int H, const int W) {
+__global__ void k_rf_quant(const float* __restrict__ yw, const size_t yw_plane_stride, const int ldy,
+                           const int transpose, uint8_t* __restrict__ dst, const size_t dst_stride,
+                           const size_t dst_plane_stride, float* __restrict__ ywout, const int H, const int W) {
   const int r = blockIdx.y;
+  yw += (size_t)blockIdx.z * yw_plane_stride;
+  dst += (size_t)blockIdx.z * dst_plane_stride;
+  if (ywout) ywout += (size_t)blockIdx.z * (size_t)H * W;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x) {
     const float v = transpose ? yw[(size_t)c * ldy + r] : yw[(size_t)r * ldy + c];
     if (ywout) ywout[(size_t)r * W + c] = v;
@@ -392,23 +413,25 @@ __global__ void k_rf_gather_rows(const float* __restrict__ src, const int ld, co
 // host side
 // ---------------------------------------------------------------------------
 struct RefPlan {
-  int H, W, L, M, Lp, ld, nbk, npairs, nsteps, nch;
+  int H, W, L, M, Lp, ld, nbk, npairs, nsteps, nch, B;
+  size_t aug_ps;         // floats between the Aug matrices of consecutive planes
   bool transpose;        // A = plane^T (portrait planes: the short side must index rows)
 };
 
-RefPlan make_plan(int H, int W) {
+RefPlan make_plan(int H, int W, int B = 1) {
   RefPlan p;
-  p.H = H; p.W = W;
+  p.H = H; p.W = W; p.B = B;
   p.transpose = H > W;
   p.L = std::min(H, W); p.M = std::max(H, W);
   p.Lp = (p.L + RP - 1) / RP * RP;
   p.ld = (p.M + p.Lp + 3) & ~3;
+  p.aug_ps = (size_t)p.Lp * p.ld;
   p.nbk = p.Lp / RB; p.npairs = p.nbk / 2; p.nsteps = p.nbk - 1;
   p.nch = (p.M + GRAM_CC - 1) / GRAM_CC;
   return p;
 }
 
-struct RefWs {           // carved out of ctx->ref_ws
+struct RefWs {           // carved out of ctx->ref_ws; every per-plane array is [B][...]
   float* aug; float* partials; float* R; int2* pairs; unsigned* maxcos; double* b2; double* q2;
   float* dvec; int* order; float* scale; float* tmp1; float* tmp2;
 };
@@ -418,10 +441,11 @@ inline size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, size_t extra_f32_b) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += a256(bytes); return o; };
-  const size_t o_aug = take((size_t)p.Lp * p.ld * 4), o_par = take((size_t)p.npairs * p.nch * RP * RP * 4),
-               o_R = take((size_t)p.npairs * RP * RP * 4), o_pairs = take((size_t)p.nsteps * p.npairs * sizeof(int2)),
-               o_mc = take(256), o_b2 = take((size_t)p.Lp * 8), o_q2 = take((size_t)p.Lp * 8),
-               o_d = take((size_t)p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
+  const size_t B = (size_t)p.B;
+  const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * RP * RP * 4),
+               o_R = take(B * p.npairs * RP * RP * 4), o_pairs = take((size_t)p.nsteps * p.npairs * sizeof(int2)),
+               o_mc = take(B * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
+               o_d = take(B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
                o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
   WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
   char* b = (char*)ctx->ref_ws;
@@ -473,43 +497,51 @@ int get_dct(wm_ctx* ctx, int n, int slot, float** out) {
   return WM_OK;
 }
 
-// block one-sided Jacobi on Aug (already loaded); on return rows of B are orthogonal.
-// sweeps_out: sweeps used (negative: bound hit).
+// block one-sided Jacobi on the B Aug matrices (already loaded); every launch covers
+// all planes (grid.z), sweeps continue until every plane's Gram matrices are diagonal
+// to CONV_COS.  sweeps_out: sweeps used (negative: bound hit).
 int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int* sweeps_out) {
   const int ncols = with_q ? p.M + p.Lp : p.M;
   int sweep = 0;
   bool done = false;
+  std::vector<unsigned> bits(p.B);
   while (!done && sweep < MAX_SWEEPS) {
-    WM_HIP(hipMemsetAsync(w.maxcos, 0, sizeof(unsigned), ctx->stream));
+    WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));
     for (int s = 0; s < p.nsteps; ++s) {
       const int2* pr = w.pairs + (size_t)s * p.npairs;
-      hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, pr, w.partials);
-      hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs), dim3(256), 0, ctx->stream, w.partials, p.nch, w.R, w.maxcos,
+      hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, pr, w.partials);
+      hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, p.B), dim3(256), 0, ctx->stream, w.partials, p.nch, w.R, w.maxcos,
                          s == 0 ? 0 : 1);
-      hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (ncols + 63) / 64), dim3(256), 0, ctx->stream, w.aug, p.ld, ncols, pr, w.R);
+      hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (ncols + 63) / 64, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld,
+                         ncols, pr, w.R);
     }
     WM_HIP(hipGetLastError());
-    unsigned bits = 0;
-    WM_HIP(hipMemcpyAsync(&bits, w.maxcos, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipMemcpyAsync(bits.data(), w.maxcos, (size_t)p.B * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
-    float mc; memcpy(&mc, &bits, 4);
     ++sweep;
-    done = mc < CONV_COS;
+    done = true;
+    for (int z = 0; z < p.B; ++z) { float mc; memcpy(&mc, &bits[z], 4); if (!(mc < CONV_COS)) done = false; }
   }
   *sweeps_out = done ? sweep : -sweep;
   return WM_OK;
 }
 
-// sigma_i = |b_i| / |q_i| for the L_p rows, sort descending -> order, sigma_sorted
-int sorted_sigma(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std::vector<double>& b2,
-                 std::vector<double>& q2, std::vector<int>& order, std::vector<float>& sig) {
-  hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, with_q ? p.Lp : 0, w.b2, w.q2);
+// row norms of every plane -> host (b2, q2 are [B][Lp])
+int fetch_norms(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std::vector<double>& b2,
+                std::vector<double>& q2) {
+  hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M,
+                     with_q ? p.Lp : 0, w.b2, w.q2);
   WM_HIP(hipGetLastError());
-  b2.resize(p.Lp); q2.resize(p.Lp);
-  WM_HIP(hipMemcpyAsync(b2.data(), w.b2, (size_t)p.Lp * 8, hipMemcpyDeviceToHost, ctx->stream));
-  WM_HIP(hipMemcpyAsync(q2.data(), w.q2, (size_t)p.Lp * 8, hipMemcpyDeviceToHost, ctx->stream));
+  b2.resize((size_t)p.B * p.Lp); q2.resize((size_t)p.B * p.Lp);
+  WM_HIP(hipMemcpyAsync(b2.data(), w.b2, b2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipMemcpyAsync(q2.data(), w.q2, q2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
   if (!with_q) std::fill(q2.begin(), q2.end(), 1.0);
+  return WM_OK;
+}
+
+// sigma_i = |b_i| / |q_i| of one plane's Lp rows, sorted descending -> order, sig[L]
+void sort_sigma(const RefPlan& p, const double* b2, const double* q2, std::vector<int>& order, std::vector<float>& sig) {
   std::vector<double> s(p.Lp);
   for (int i = 0; i < p.Lp; ++i) s[i] = sqrt(b2[i] / (q2[i] > 0 ? q2[i] : 1.0));
   order.resize(p.Lp);
@@ -517,15 +549,21 @@ int sorted_sigma(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return s[a] > s[b]; });
   sig.resize(p.L);
   for (int k = 0; k < p.L; ++k) sig[k] = (float)s[order[k]];
+}
+
+int check_ref_args(wm_ctx* ctx, const void* plane, int n_planes, int H, int W, int row_stride, size_t plane_stride) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
+  if (n_planes <= 0 || n_planes > 65535) return set_err(WM_ERR_BADARG, "n_planes must be in 1..65535");
+  if (!plane) return set_err(WM_ERR_BADARG, "plane pointer is NULL");
+  if (row_stride < W) return set_err(WM_ERR_BADARG, "row_stride < W");
+  if (n_planes > 1 && plane_stride < (size_t)row_stride * (H - 1) + W)
+    return set_err(WM_ERR_BADARG, "plane_stride smaller than one plane");
   return WM_OK;
 }
 
-int check_ref_args(wm_ctx* ctx, const void* plane, int H, int W, int row_stride) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
-  if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
-  if (!plane) return set_err(WM_ERR_BADARG, "plane pointer is NULL");
-  if (row_stride < W) return set_err(WM_ERR_BADARG, "row_stride < W");
-  return WM_OK;
+inline size_t span_of(int n_planes, int H, int W, int row_stride, size_t plane_stride) {
+  return (size_t)(n_planes - 1) * plane_stride + (size_t)(H - 1) * row_stride + (size_t)W;
 }
 
 }  // namespace
@@ -535,80 +573,108 @@ int check_ref_args(wm_ctx* ctx, const void* plane, int H, int W, int row_stride)
 // ===========================================================================
 extern "C" {
 
-int wm_ref_sigma_u8(wm_ctx* ctx, const uint8_t* plane, float* sigma, int H, int W, int row_stride) {
-  WM_TRY(check_ref_args(ctx, plane, H, W, row_stride));
+int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H, int W,
+                           int row_stride, size_t plane_stride) {
+  WM_TRY(check_ref_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
   if (!sigma) return set_err(WM_ERR_BADARG, "sigma is NULL");
-  const RefPlan p = make_plan(H, W);
+  const RefPlan p = make_plan(H, W, n_planes);
   RefWs w;
-  const size_t n_in = (size_t)H * row_stride;
-  WM_TRY(plan_workspace(ctx, p, w, (n_in + 3) / 4, 0));
+  const size_t n_in = span_of(n_planes, H, W, row_stride, plane_stride);
+  WM_TRY(plan_workspace(ctx, p, w, (n_in + 3) / 4 + 4, 0));
   WM_TRY(upload_pairs(ctx, p, w));
   uint8_t* d_in = (uint8_t*)w.tmp1;
-  WM_HIP(hipMemcpyAsync(d_in, plane, n_in, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
-                     p.transpose ? 1 : 0, w.aug, p.ld, p.L, p.Lp, p.M);
+  WM_HIP(hipMemcpyAsync(d_in, planes, n_in, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
+                     plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
   int sweeps = 0;
   WM_TRY(jacobi_rows(ctx, p, w, false, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
-  std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
-  WM_TRY(sorted_sigma(ctx, p, w, false, b2, q2, order, sig));
-  memcpy(sigma, sig.data(), (size_t)p.L * 4);
+  std::vector<double> b2, q2;
+  WM_TRY(fetch_norms(ctx, p, w, false, b2, q2));
+  std::vector<int> order; std::vector<float> sig;
+  for (int z = 0; z < n_planes; ++z) {
+    sort_sigma(p, &b2[(size_t)z * p.Lp], &q2[(size_t)z * p.Lp], order, sig);
+    memcpy(sigma + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
+  }
+  return WM_OK;
+}
+
+int wm_ref_sigma_u8(wm_ctx* ctx, const uint8_t* plane, float* sigma, int H, int W, int row_stride) {
+  return wm_ref_sigma_planes_u8(ctx, plane, sigma, 1, H, W, row_stride, (size_t)H * row_stride);
+}
+
+int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,
+                           float* yw, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                           size_t sigma_w_plane_stride, float alpha, int K) {
+  WM_TRY(check_ref_args(ctx, host, n_planes, H, W, row_stride, plane_stride));
+  if (!sigma_w || !stego || !sigma_c) return set_err(WM_ERR_BADARG, "NULL argument");
+  const RefPlan p = make_plan(H, W, n_planes);
+  if (K < 0 || K > p.L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
+  RefWs w;
+  const size_t n_in = span_of(n_planes, H, W, row_stride, plane_stride);
+  const size_t n_in16 = (n_in + 15) & ~(size_t)15;
+  const size_t yw_elems = yw ? (size_t)n_planes * H * W : 0;
+  // tmp1: uint8 input + output spans (+ dense float Yw for the caller); tmp2: Yw in A layout [B][L][M]
+  WM_TRY(plan_workspace(ctx, p, w, (2 * n_in16) / 4 + 8 + yw_elems, (size_t)n_planes * p.L * p.M));
+  WM_TRY(upload_pairs(ctx, p, w));
+  uint8_t* d_in = (uint8_t*)w.tmp1;
+  uint8_t* d_out = d_in + n_in16;
+  float* d_ywout = yw ? (float*)(d_out + n_in16) : nullptr;
+  float* d_yw = w.tmp2;
+  const size_t yw_ps = (size_t)p.L * p.M;
+  WM_HIP(hipMemcpyAsync(d_in, host, n_in, hipMemcpyHostToDevice, ctx->stream));
+  if (stego != host) WM_HIP(hipMemcpyAsync(d_out, stego, n_in, hipMemcpyHostToDevice, ctx->stream));
+  else WM_HIP(hipMemcpyAsync(d_out, d_in, n_in, hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
+                     plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
+  // Yw starts as A itself (exactly the pixels): copy the first L rows of every B part before rotating
+  for (int z = 0; z < n_planes; ++z)
+    WM_HIP(hipMemcpy2DAsync(d_yw + (size_t)z * yw_ps, (size_t)p.M * 4, w.aug + (size_t)z * p.aug_ps, (size_t)p.ld * 4,
+                            (size_t)p.M * 4, p.L, hipMemcpyDeviceToDevice, ctx->stream));
+  int sweeps = 0;
+  WM_TRY(jacobi_rows(ctx, p, w, true, &sweeps));
+  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
+  std::vector<double> b2, q2;
+  WM_TRY(fetch_norms(ctx, p, w, true, b2, q2));
+  // d_i = alpha * sw[rank(i)] / (|b_i| |q_i|), rank < K        (S_[:K] = Sc[:K] + alpha*Sw[:K])
+  std::vector<float> d((size_t)n_planes * p.Lp, 0.0f);
+  std::vector<int> order; std::vector<float> sig;
+  for (int z = 0; z < n_planes; ++z) {
+    const double* pb = &b2[(size_t)z * p.Lp]; const double* pq = &q2[(size_t)z * p.Lp];
+    sort_sigma(p, pb, pq, order, sig);
+    memcpy(sigma_c + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
+    const float* sw = sigma_w + (size_t)z * sigma_w_plane_stride;
+    for (int k = 0; k < std::min(K, p.L); ++k) {
+      const int i = order[k];
+      const double den = sqrt(pb[i] * pq[i]);
+      d[(size_t)z * p.Lp + i] = den > 0.0 ? (float)((double)alpha * (double)sw[k] / den) : 0.0f;
+    }
+  }
+  WM_HIP(hipMemcpyAsync(w.dvec, d.data(), d.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, w.dvec);
+  // Yw += Qt^T (diag(d) B):   [L x Lp]^T-view of Qt (rows i, cols r < L) times [Lp x M]
+  for (int z = 0; z < n_planes; ++z)
+    WM_TRY(sgemm(ctx, true, false, p.L, p.M, p.Lp, 1.0f, w.aug + (size_t)z * p.aug_ps + p.M, p.ld,
+                 w.aug + (size_t)z * p.aug_ps, p.ld, 1.0f, d_yw + (size_t)z * yw_ps, p.M));
+  hipLaunchKernelGGL(k_rf_quant, dim3(8, H, p.B), dim3(256), 0, ctx->stream, d_yw, yw_ps, p.M, p.transpose ? 1 : 0,
+                     d_out, (size_t)row_stride, plane_stride, d_ywout, H, W);
+  WM_HIP(hipGetLastError());
+  WM_HIP(hipMemcpyAsync(stego, d_out, n_in, hipMemcpyDeviceToHost, ctx->stream));
+  if (yw) WM_HIP(hipMemcpyAsync(yw, d_ywout, yw_elems * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
   return WM_OK;
 }
 
 int wm_ref_embed_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,
                     float* yw, int H, int W, int row_stride, float alpha, int K) {
-  WM_TRY(check_ref_args(ctx, host, H, W, row_stride));
-  if (!sigma_w || !stego || !sigma_c) return set_err(WM_ERR_BADARG, "NULL argument");
-  const RefPlan p = make_plan(H, W);
-  if (K < 0 || K > p.L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
-  RefWs w;
-  const size_t n_in = (size_t)H * row_stride;
-  // tmp1: uint8 input + output planes; tmp2: Yw (float, A layout L x M)
-  WM_TRY(plan_workspace(ctx, p, w, (2 * n_in + 7) / 4 + (yw ? (size_t)H * W : 0), (size_t)p.L * p.M));
-  WM_TRY(upload_pairs(ctx, p, w));
-  uint8_t* d_in = (uint8_t*)w.tmp1;
-  uint8_t* d_out = d_in + ((n_in + 15) & ~(size_t)15);
-  float* d_ywout = yw ? (float*)(d_out + ((n_in + 15) & ~(size_t)15)) : nullptr;
-  float* d_yw = w.tmp2;
-  WM_HIP(hipMemcpyAsync(d_in, host, n_in, hipMemcpyHostToDevice, ctx->stream));
-  if (stego != host) WM_HIP(hipMemcpyAsync(d_out, stego, n_in, hipMemcpyHostToDevice, ctx->stream));
-  else WM_HIP(hipMemcpyAsync(d_out, d_in, n_in, hipMemcpyDeviceToDevice, ctx->stream));
-  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
-                     p.transpose ? 1 : 0, w.aug, p.ld, p.L, p.Lp, p.M);
-  // Yw starts as A itself (exactly the pixels): copy the first L rows of the B part before rotating
-  WM_HIP(hipMemcpy2DAsync(d_yw, (size_t)p.M * 4, w.aug, (size_t)p.ld * 4, (size_t)p.M * 4, p.L,
-                          hipMemcpyDeviceToDevice, ctx->stream));
-  int sweeps = 0;
-  WM_TRY(jacobi_rows(ctx, p, w, true, &sweeps));
-  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
-  std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
-  WM_TRY(sorted_sigma(ctx, p, w, true, b2, q2, order, sig));
-  memcpy(sigma_c, sig.data(), (size_t)p.L * 4);
-  // d_i = alpha * sw[rank(i)] / (sigma_i |q_i|^2), rank < K        (S_[:K] = Sc[:K] + alpha*Sw[:K])
-  std::vector<float> d(p.Lp, 0.0f);
-  for (int k = 0; k < std::min(K, p.L); ++k) {
-    const int i = order[k];
-    const double den = sqrt(b2[i] * q2[i]);        // sigma_i * |q_i|^2 = |b_i| |q_i|
-    d[i] = den > 0.0 ? (float)((double)alpha * (double)sigma_w[k] / den) : 0.0f;
-  }
-  WM_HIP(hipMemcpyAsync(w.dvec, d.data(), (size_t)p.Lp * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, p.Lp), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, w.dvec);
-  // Yw += Qt^T (diag(d) B):   [L x Lp]^T-view of Qt (rows i, cols r < L) times [Lp x M]
-  WM_TRY(sgemm(ctx, true, false, p.L, p.M, p.Lp, 1.0f, w.aug + p.M, p.ld, w.aug, p.ld, 1.0f, d_yw, p.M));
-  hipLaunchKernelGGL(k_rf_quant, dim3(8, H), dim3(256), 0, ctx->stream, d_yw, p.M, p.transpose ? 1 : 0, d_out,
-                     (size_t)row_stride, d_ywout, H, W);
-  WM_HIP(hipGetLastError());
-  WM_HIP(hipMemcpyAsync(stego, d_out, n_in, hipMemcpyDeviceToHost, ctx->stream));
-  if (yw) WM_HIP(hipMemcpyAsync(yw, d_ywout, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
-  WM_HIP(hipStreamSynchronize(ctx->stream));
-  return WM_OK;
+  return wm_ref_embed_planes_u8(ctx, host, sigma_w, stego, sigma_c, yw, 1, H, W, row_stride,
+                                (size_t)H * row_stride, 0, alpha, K);
 }
 
 // thin SVD of dct2(plane) (apply_dct != 0) or of the plane itself: U [H x L], S [L], Vt [L x W]
 int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* Vt, int H, int W,
                    int row_stride, int apply_dct) {
-  WM_TRY(check_ref_args(ctx, plane, H, W, row_stride));
+  WM_TRY(check_ref_args(ctx, plane, 1, H, W, row_stride, (size_t)H * row_stride));
   if (!U || !S || !Vt) return set_err(WM_ERR_BADARG, "U/S/Vt is NULL");
   const RefPlan p = make_plan(H, W);
   RefWs w;
@@ -628,13 +694,14 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
     WM_TRY(sgemm(ctx, false, true, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_c, W));              // (D_H X) D_W^T
     src = d_c; src_stride = (size_t)W;
   }
-  hipLaunchKernelGGL((k_rf_load<float>), dim3(8, p.Lp), dim3(256), 0, ctx->stream, src, src_stride,
-                     p.transpose ? 1 : 0, w.aug, p.ld, p.L, p.Lp, p.M);
+  hipLaunchKernelGGL((k_rf_load<float>), dim3(8, p.Lp, 1), dim3(256), 0, ctx->stream, src, src_stride, (size_t)0,
+                     p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
   int sweeps = 0;
   WM_TRY(jacobi_rows(ctx, p, w, true, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
-  WM_TRY(sorted_sigma(ctx, p, w, true, b2, q2, order, sig));
+  WM_TRY(fetch_norms(ctx, p, w, true, b2, q2));
+  sort_sigma(p, b2.data(), q2.data(), order, sig);
   memcpy(S, sig.data(), (size_t)p.L * 4);
   // short-side factor: columns q_i/|q_i|   (rows of Qt), long-side factor: rows b_i/|b_i|
   std::vector<float> sq(p.L), sb(p.L);
@@ -669,7 +736,7 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
 // extract: sigma(stego) -> Sw_hat -> Uw[:L,:L] diag(Sw_hat) Vwt[:L,:L], zero-padded -> idct2
 int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw, const float* Vwt,
                       float* out, int H, int W, int row_stride, float alpha, int K) {
-  WM_TRY(check_ref_args(ctx, stego, H, W, row_stride));
+  WM_TRY(check_ref_args(ctx, stego, 1, H, W, row_stride, (size_t)H * row_stride));
   if (!sigma_c || !Uw || !Vwt || !out) return set_err(WM_ERR_BADARG, "NULL argument");
   const int L = std::min(H, W);
   if (K < 0 || K > L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
@@ -705,7 +772,7 @@ int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, c
 // detect: _nc(Sw[:L], (S_cw - Sc) / max(alpha, 1e-8))     single:297-301, 284-289
 int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
                      double* score, int H, int W, int row_stride, float alpha) {
-  WM_TRY(check_ref_args(ctx, stego, H, W, row_stride));
+  WM_TRY(check_ref_args(ctx, stego, 1, H, W, row_stride, (size_t)H * row_stride));
   if (!sigma_c || !sigma_w || !score) return set_err(WM_ERR_BADARG, "NULL argument");
   const int L = std::min(H, W);
   std::vector<float> s_cw(L);

@@ -118,14 +118,17 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
         common["k_floor"] = np.int32(k_floor)
     if color:
         meta = dict(mode="color", **common)
-        planes = []
-        for ch, n in enumerate("bgr"):                                     # single:122-147
+        Sws = []
+        for ch, n in enumerate("bgr"):                                     # single:123-134
             w_s = hg.permute(wm[..., ch].astype(np.float32), idx)
-            U, S, Vt = ctx.ref_svd(w_s, apply_dct=True)                    # single:131-134
-            st, Sc, _ = ctx.ref_embed(np.ascontiguousarray(cover[..., ch]), S, alpha, K)
-            planes.append(st)
-            meta["S" + n] = Sc; meta["UW" + n] = U; meta["VW" + n + "t"] = Vt; meta["SW" + n] = S
-        stego = np.stack(planes, axis=-1)
+            U, S, Vt = ctx.ref_svd(w_s, apply_dct=True)
+            meta["UW" + n] = U; meta["VW" + n + "t"] = Vt; meta["SW" + n] = S
+            Sws.append(S)
+        hosts = np.ascontiguousarray(np.moveaxis(cover, -1, 0))            # b, g, r planes, one batched call
+        st, Sc, _ = ctx.ref_embed_planes(hosts, np.stack(Sws), alpha, K)   # single:127-147
+        for ch, n in enumerate("bgr"):
+            meta["S" + n] = Sc[ch]
+        stego = np.ascontiguousarray(np.moveaxis(st, 0, -1))
         digest = hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"], meta["UWb"], meta["UWg"], meta["UWr"],
                                       meta["VWbt"], meta["VWgt"], meta["VWrt"]])
         meta["digest"] = np.frombuffer(digest, dtype=np.uint8)

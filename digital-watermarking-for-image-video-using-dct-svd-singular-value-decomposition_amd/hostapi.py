@@ -70,6 +70,8 @@ SIGNATURES = {
     "wm_detect_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f],
     "wm_ref_embed_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_sigma_u8": [_vp, _vp, _vp, _i, _i, _i],
+    "wm_ref_embed_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_ref_sigma_planes_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
     "wm_ref_svd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_detect_u8": [_vp, _vp, _vp, _vp, C.POINTER(C.c_double), _i, _i, _i, _f],
@@ -362,6 +364,32 @@ class Context:
         self._call("wm_ref_embed_u8", _vp(host.ctypes.data), _vp(sw.ctypes.data), _vp(stego.ctypes.data),
                    _vp(sc.ctypes.data), _vp(yw.ctypes.data) if want_yw else None, H, W, W, float(alpha), int(K))
         return stego, sc, yw
+
+    def ref_embed_planes(self, hosts: np.ndarray, sigma_w: np.ndarray, alpha: float, K: int, want_yw: bool = False):
+        """hosts uint8 [N, H, W]; sigma_w [L] (shared) or [N, L].  All planes share every launch."""
+        if hosts.dtype != np.uint8 or hosts.ndim != 3:
+            raise ValueError("hosts must be uint8 [N, H, W]")
+        hosts = np.ascontiguousarray(hosts)
+        n, H, W = hosts.shape
+        L = min(H, W)
+        sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
+        if sw.shape not in ((L,), (n, L)):
+            raise ValueError(f"sigma_w must have shape ({L},) or ({n}, {L})")
+        stego = np.empty_like(hosts); sc = np.empty((n, L), np.float32)
+        yw = np.empty((n, H, W), np.float32) if want_yw else None
+        self._call("wm_ref_embed_planes_u8", _vp(hosts.ctypes.data), _vp(sw.ctypes.data), _vp(stego.ctypes.data),
+                   _vp(sc.ctypes.data), _vp(yw.ctypes.data) if want_yw else None, n, H, W, W, H * W,
+                   L if sw.ndim == 2 else 0, float(alpha), int(K))
+        return stego, sc, yw
+
+    def ref_sigma_planes(self, planes: np.ndarray) -> np.ndarray:
+        if planes.dtype != np.uint8 or planes.ndim != 3:
+            raise ValueError("planes must be uint8 [N, H, W]")
+        planes = np.ascontiguousarray(planes)
+        n, H, W = planes.shape
+        s = np.empty((n, min(H, W)), np.float32)
+        self._call("wm_ref_sigma_planes_u8", _vp(planes.ctypes.data), _vp(s.ctypes.data), n, H, W, W, H * W)
+        return s
 
     def ref_sigma(self, plane: np.ndarray) -> np.ndarray:
         if plane.dtype != np.uint8 or plane.ndim != 2:

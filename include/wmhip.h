@@ -171,6 +171,16 @@ int wm_ref_embed_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint
 /* Replaces  _, S_cw, _ = np.linalg.svd(dct2(Y))  (single:205, 297).  sigma [L]. */
 int wm_ref_sigma_u8(wm_ctx* ctx, const uint8_t* plane, float* sigma, int H, int W, int row_stride);
 
+/* Batched forms: n_planes planes (B,G,R of a colour image - single:127-147 - or frames
+ * of a video) go through every launch together (the per-plane SVD is latency-bound on
+ * its own).  sigma_w: plane p reads sigma_w + p * sigma_w_plane_stride (0 = shared);
+ * sigma_c / sigma: [n_planes][L]; yw: [n_planes][H][W]. */
+int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego,
+                           float* sigma_c, float* yw, int n_planes, int H, int W, int row_stride,
+                           size_t plane_stride, size_t sigma_w_plane_stride, float alpha, int K);
+int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H, int W,
+                           int row_stride, size_t plane_stride);
+
 /* Replaces  Wm = dct2(wy_s); Uw, Sw, Vwt = np.linalg.svd(Wm, full_matrices=False)
  * (single:173, 131-134) when apply_dct != 0 (plain thin SVD of the plane otherwise).
  *   U [H][L], S [L], Vt [L][W]. */

@@ -54,3 +54,27 @@ def test_fullframe_watermark_svd_and_extract(gpu_ctx, H, W):
     w2 = gpu_ctx.ref_extract(st, sc, U, Vt, alpha, ref["K"])
     hh = min(H, W)
     assert np.corrcoef(w2[:hh, :hh].ravel(), wo[:hh, :hh].ravel())[0, 1] > 0.98
+
+
+def test_fullframe_batched_planes_equal_single(gpu_ctx):
+    """B,G,R planes / frames through one set of launches (grid.z = plane): same results
+    as plane-by-plane, with per-plane or shared watermark sigma."""
+    H, W, alpha = 96, 160, 0.18
+    rng = np.random.default_rng(11)
+    hosts = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    sws = np.sort(rng.uniform(10, 5000, (3, H)).astype(np.float32), axis=1)[:, ::-1].copy()
+    K = 57
+    st, sc, yw = gpu_ctx.ref_embed_planes(hosts, sws, alpha, K, want_yw=True)
+    for p in range(3):
+        s1, c1, y1 = gpu_ctx.ref_embed(hosts[p], sws[p], alpha, K, want_yw=True)
+        assert np.abs(st[p].astype(int) - s1.astype(int)).max() <= 1
+        assert np.max(np.abs(sc[p] - c1)) / c1[0] < 1e-5 and np.abs(yw[p] - y1).max() < 2e-2
+        ref = o.embed_plane(hosts[p].astype(np.float32), None, alpha, 0.0, None, k_floor=K,
+                            wm_svd=(None, sws[p], None))
+        assert np.abs(st[p].astype(int) - ref["stego"].astype(int)).max() <= 1
+    st2, _, _ = gpu_ctx.ref_embed_planes(hosts, sws[0], alpha, K)                 # shared sigma_w
+    s0, _, _ = gpu_ctx.ref_embed(hosts[2], sws[0], alpha, K)
+    assert np.abs(st2[2].astype(int) - s0.astype(int)).max() <= 1
+    sig = gpu_ctx.ref_sigma_planes(st)
+    for p in range(3):
+        assert np.max(np.abs(sig[p] - gpu_ctx.ref_sigma(st[p]))) / sig[p, 0] < 1e-5

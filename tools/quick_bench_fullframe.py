@@ -24,6 +24,10 @@ dt, (st, sc, _) = t(lambda: ctx.ref_embed(host, S, alpha, K)); print(f"gpu embed
 dt, s = t(lambda: ctx.ref_sigma(st)); print(f"gpu sigma       {dt*1e3:9.1f} ms", flush=True)
 dt, w = t(lambda: ctx.ref_extract(st, sc, U, Vt, alpha, K)); print(f"gpu extract     {dt*1e3:9.1f} ms", flush=True)
 dt, score = t(lambda: ctx.ref_detect(st, sc, S, alpha)); print(f"gpu detect      {dt*1e3:9.1f} ms  score {score:.4f}", flush=True)
+for nb in (3, 8):
+    hosts = np.random.default_rng(9).integers(0, 256, (nb, H, W), dtype=np.uint8)
+    dt, _ = t(lambda: ctx.ref_embed_planes(hosts, S, alpha, K), 1)
+    print(f"gpu embed x{nb} planes batched {dt*1e3:9.1f} ms  ({dt*1e3/nb:.1f} ms/plane)", flush=True)
 if a.cpu:
     t0 = time.perf_counter(); e = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, None); t1 = time.perf_counter()
     print(f"cpu oracle embed (2 SVDs) {(t1-t0)*1e3:9.1f} ms")
