@@ -236,8 +236,12 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
     }
   }
   if (sweeps < 0) atomicOr(status, 1);
-  store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
-  store_raw<ALIGNED>(stego + off, g.row_stride, out);
+  // flagged tiles are left untouched: stego may alias host (in-place embedding) and the
+  // fallback kernel must still read the original pixels
+  if (!deficient) {
+    store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
+    store_raw<ALIGNED>(stego + off, g.row_stride, out);
+  }
 }
 
 // Literal chain with orthonormal completion (wm::embed_tile_completed) for the

@@ -162,3 +162,20 @@ def test_unaligned_and_strided_planes(gpu_ctx, hostapi):
         assert _rel_sigma(sc[p], ref["Sc"]) < SIGMA_RTOL
     mask = np.ones_like(big, bool); mask[:, 3:51, 5:77] = False
     assert np.all(out_big[mask] == 7)
+
+
+def test_in_place_embed_with_deficient_tiles(gpu_ctx):
+    """stego may alias host (include/wmhip.h): flagged tiles must be embedded once, from
+    the original pixels, by the fallback kernel."""
+    import ctypes as C
+    from test_host_harness import _degenerate_image
+    img, _ = _degenerate_image()
+    H, W = img.shape
+    wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+    Uo, So, Vto = o.watermark_decompose(wys, 8)
+    sw = np.ascontiguousarray(So.reshape(-1, 8))
+    want, sc_want, _ = gpu_ctx.embed_tiles(img, So, 0.15)
+    buf = img.copy(); sc = np.empty((sw.shape[0], 8), np.float32)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    gpu_ctx._call("wm_embed_tiles_u8", vp(buf), vp(sw), vp(buf), vp(sc), None, 1, H, W, W, H * W, 0, 0.15, 8)
+    assert np.array_equal(buf, want) and np.allclose(sc.reshape(sc_want.shape), sc_want)
