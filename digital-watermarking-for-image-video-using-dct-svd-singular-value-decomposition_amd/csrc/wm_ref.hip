@@ -17,6 +17,7 @@
 // DCT-domain factors (watermark side / extract) use plain tiled SGEMMs with the
 // DCT basis matrices.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -33,6 +34,7 @@ constexpr int RB = 32;        // rows per Jacobi block
 constexpr int RP = 2 * RB;    // rows per block pair
 constexpr int GRAM_CC = 128;  // columns per Gram partial
 constexpr int MAX_SWEEPS = 40;
+constexpr int FULL_INNER_SWEEPS = 0;   // outer sweeps whose every step runs the full 63-step inner schedule
 constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to ~eps*sqrt(M)
 
 // ---------------------------------------------------------------------------
@@ -505,13 +507,14 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
   int sweep = 0;
   bool done = false;
   std::vector<unsigned> bits(p.B);
+  static const int full_sweeps = getenv("WM_RF_FULL_SWEEPS") ? atoi(getenv("WM_RF_FULL_SWEEPS")) : FULL_INNER_SWEEPS;
   while (!done && sweep < MAX_SWEEPS) {
     WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));
     for (int s = 0; s < p.nsteps; ++s) {
       const int2* pr = w.pairs + (size_t)s * p.npairs;
       hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, pr, w.partials);
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, p.B), dim3(256), 0, ctx->stream, w.partials, p.nch, w.R, w.maxcos,
-                         s == 0 ? 0 : 1);
+                         (s == 0 || sweep < full_sweeps) ? 0 : 1);
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (ncols + 63) / 64, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld,
                          ncols, pr, w.R);
     }

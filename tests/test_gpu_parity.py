@@ -179,3 +179,17 @@ def test_in_place_embed_with_deficient_tiles(gpu_ctx):
     vp = lambda a: C.c_void_p(a.ctypes.data)
     gpu_ctx._call("wm_embed_tiles_u8", vp(buf), vp(sw), vp(buf), vp(sc), None, 1, H, W, W, H * W, 0, 0.15, 8)
     assert np.array_equal(buf, want) and np.allclose(sc.reshape(sc_want.shape), sc_want)
+
+
+def test_results_are_bitwise_reproducible(gpu_ctx):
+    """No float atomics anywhere in the numeric path: two runs give identical bytes."""
+    host, wys = _inputs(256, 384)
+    U, S, Vt = gpu_ctx.svd_tiles(wys)
+    a = gpu_ctx.embed_tiles(host, S, 0.15, want_yw=True)
+    b = gpu_ctx.embed_tiles(host, S, 0.15, want_yw=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert np.array_equal(gpu_ctx.extract_tiles(a[0], a[1], U, Vt, 0.15), gpu_ctx.extract_tiles(b[0], b[1], U, Vt, 0.15))
+    assert gpu_ctx.detect_tiles(a[0], a[1], S, 0.15)[0] == gpu_ctx.detect_tiles(a[0], a[1], S, 0.15)[0]
+    f1 = gpu_ctx.ref_embed(host, np.sort(S.reshape(-1))[::-1][:256].copy(), 0.15, 100)
+    f2 = gpu_ctx.ref_embed(host, np.sort(S.reshape(-1))[::-1][:256].copy(), 0.15, 100)
+    assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
