@@ -117,8 +117,8 @@ int wm_svd_tiles_f32(wm_ctx* ctx, const float* planes, float* U, float* S, float
  * Sw_hat = (S_cw - Sc) / max(alpha,1e-8); Sw_hat[K:] = 0 (single:212-213) ->
  * Uw @ diag(Sw_hat) @ Vwt (single:214) -> idct2 (single:218).
  *   sigma_c  [n_planes][n_tiles][8]
- *   Uw, Vwt  [..][n_tiles][8][8]; plane p reads + p * uv_plane_stride
- *            (0 => shared by all planes)
+ *   Uw, Vwt  [..][n_tiles][8][8]; plane p reads tile index p * uv_plane_stride + t,
+ *            uv_plane_stride in TILES: n_tiles (per plane) or 0 (shared by all planes)
  *   out      [n_planes][H][W] float32 scrambled-watermark estimate wy_s
  *            (dense, row stride W) - input of _unpermute (single:220). */
 int wm_extract_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
