@@ -136,15 +136,6 @@ def device_count() -> int:
     return n.value
 
 
-def _ptr(x) -> Optional[int]:
-    """numpy array -> host address; int -> passed through (device pointer)."""
-    if x is None:
-        return None
-    if isinstance(x, np.ndarray):
-        return x.ctypes.data
-    return int(x)
-
-
 def _plane_layout(a: np.ndarray):
     """(n_planes, H, W, row_stride, plane_stride) in elements of a [H,W] or
     [N,H,W] array whose last axis is contiguous."""
@@ -154,11 +145,15 @@ def _plane_layout(a: np.ndarray):
         raise ValueError("planes must be [H, W] or [n_planes, H, W]")
     n, H, W = a.shape
     it = a.itemsize
-    if W and a.strides[2] != it:
+    if W > 1 and a.strides[2] != it:
         raise ValueError("last axis must be contiguous")
-    rs = a.strides[1] // it if H > 1 else max(W, a.strides[1] // it if a.strides[1] else W)
-    ps = a.strides[0] // it if n > 1 else rs * H
-    return n, H, W, max(rs, W), ps
+    if any(st < 0 or st % it for st in a.strides):
+        raise ValueError("negative or unaligned strides are not supported")
+    rs = max(W, a.strides[1] // it) if H > 1 else W       # elements between rows
+    ps = a.strides[0] // it if n > 1 else rs * H           # elements between planes
+    if n > 1 and ps < rs * (H - 1) + W:
+        raise ValueError("planes overlap")
+    return n, H, W, rs, ps
 
 
 class Context:
