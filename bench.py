@@ -184,6 +184,7 @@ def main():
         value = world * F * a.steps / dt
         alg_bytes = 3.0 * H * W * F                                  # 3 B per pixel per plane
         achieved = alg_bytes / (embed_ms_avg * 1e-3) / 1e9
+        valu = None
         traffic = None    # HBM bytes per embed launch from the committed PMC passes (profiles/), scaled by frames
         pmc = os.path.join(ROOT, "profiles", "pmc_embed_latest.json")
         if os.path.exists(pmc):
@@ -191,6 +192,9 @@ def main():
                 j = json.load(open(pmc))
                 if (j.get("H"), j.get("W")) == (H, W):
                     traffic = j["hbm_bytes_per_launch_at_bench_shape"] * F / j["frames_per_launch"]
+                if "valu_busy_fraction" in j:      # what actually binds this kernel (PMC pass, profiles/)
+                    valu = {"busy_frac_pmc": j["valu_busy_fraction"], "insts_per_64_tile_wave": j["valu_insts_per_wave"],
+                            "effective_clock_GHz": j["effective_clock_GHz"], "source": j.get("source")}
             except Exception:
                 traffic = None
         out = {
@@ -206,7 +210,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_embed_tiles (+ its fallback pass)", "launch_ms": embed_ms_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "path is VALU-bound (~1e4 FP32 lane-ops per 64-px tile): see DESIGN.md"},
+                         "valu": valu,
+                         "note": "path is FP32-VALU-bound (~7.5e3 VALU instructions per 64-tile wave against 192 B "
+                                 "per tile): the HBM fraction cannot approach 1, see DESIGN.md 3.3"},
         }
         if world == 1 and a.cpu_frames > 0:
             n = min(a.cpu_frames, F)
