@@ -232,3 +232,26 @@ def test_structured_tiles_with_repeated_singular_values(gpu_ctx):
             assert abs(got_scores[p]) < 1.0 + 1e-9
             continue
         assert abs(got_scores[p] - o.detect_plane(stego[p].astype(np.float32), sc[p], So, alpha, 8)) < 2e-3
+
+
+def test_two_contexts_from_two_threads(hostapi):
+    """one opaque handle per device/stream, independently usable from two
+    threads (ctypes releases the GIL during the calls)."""
+    import threading
+    host, wys = _inputs(256, 384)
+    ref = o.embed_plane(host.astype(np.float32), wys, 0.15, 0.6, tile=8)
+    results = [None, None]
+
+    def work(i):
+        with hostapi.Context(0) as c:
+            for _ in range(5):
+                st, sc, _ = c.embed_tiles(host, ref["Sw"], 0.15)
+                w = c.extract_tiles(st, sc, ref["Uw"], ref["Vwt"], 0.15)
+            results[i] = (st, sc, w)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert results[0] is not None and results[1] is not None
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(results[0][0].astype(int) - ref["stego"].astype(int)).max() <= 1
