@@ -43,6 +43,7 @@ struct wm_ctx {
   size_t ref_ws_bytes = 0;
   float* dct_mat[2] = {nullptr, nullptr};   // cached DCT-II basis matrices (device), by size
   int dct_n[2] = {0, 0};
+  int ref_last_sweeps = 0;        // outer Jacobi sweeps of the last full-frame SVD (diagnostics)
   hipEvent_t ev[wmi::N_EVENTS] = {};
 };
 

@@ -385,6 +385,14 @@ __global__ void k_rf_scale_rows(float* __restrict__ aug, const size_t aug_plane_
     aug[(size_t)i * ld + j] *= s;
 }
 
+// dst[r][k] = src[r][k] * d[k]   (L x L, "U @ diag(d)")
+__global__ void k_rf_scale_cols(const float* __restrict__ src, float* __restrict__ dst, const int L,
+                                const float* __restrict__ d) {
+  const int r = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < L; k += gridDim.x * blockDim.x)
+    dst[(size_t)r * L + k] = src[(size_t)r * L + k] * d[k];
+}
+
 // Yw (float, logical A layout L x M or its transpose) -> clip/truncate -> uint8 plane; optional float copy
 __global__ void k_rf_quant(const float* __restrict__ yw, const size_t yw_plane_stride, const int ldy,
                            const int transpose, uint8_t* __restrict__ dst, const size_t dst_stride,
@@ -526,6 +534,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
     for (int z = 0; z < p.B; ++z) { float mc; memcpy(&mc, &bits[z], 4); if (!(mc < CONV_COS)) done = false; }
   }
   *sweeps_out = done ? sweep : -sweep;
+  ctx->ref_last_sweeps = sweep;
   return WM_OK;
 }
 
@@ -736,39 +745,60 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
   return WM_OK;
 }
 
-// extract: sigma(stego) -> Sw_hat -> Uw[:L,:L] diag(Sw_hat) Vwt[:L,:L], zero-padded -> idct2
-int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw, const float* Vwt,
-                      float* out, int H, int W, int row_stride, float alpha, int K) {
-  WM_TRY(check_ref_args(ctx, stego, 1, H, W, row_stride, (size_t)H * row_stride));
+// extract: sigma(stego) -> Sw_hat -> Uw[:L,:L] diag(Sw_hat) Vwt[:L,:L], zero-padded -> idct2.
+// n_planes stego planes share one watermark decomposition (frames of a video): their SVDs
+// run batched, the three GEMMs per plane follow.
+int wm_ref_extract_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                             const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                             size_t plane_stride, float alpha, int K) {
+  WM_TRY(check_ref_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
   if (!sigma_c || !Uw || !Vwt || !out) return set_err(WM_ERR_BADARG, "NULL argument");
   const int L = std::min(H, W);
   if (K < 0 || K > L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
-  std::vector<float> s_cw(L);
-  WM_TRY(wm_ref_sigma_u8(ctx, stego, s_cw.data(), H, W, row_stride));          // single:205
+  std::vector<float> s_cw((size_t)n_planes * L);
+  WM_TRY(wm_ref_sigma_planes_u8(ctx, stego, s_cw.data(), n_planes, H, W, row_stride, plane_stride));   // single:205
   const float a = fmaxf(alpha, 1e-8f);
-  std::vector<float> sh(L, 0.0f);
-  for (int i = 0; i < K; ++i) sh[i] = (s_cw[i] - sigma_c[i]) / a;                // single:212-213
-  // Wm_hat[:L,:L] = (Uw[:L,:L] * sh) @ Vwt[:L,:L]                              single:214 (the [:L,:L] quirk)
   const RefPlan p = make_plan(H, W);
   RefWs w;
-  WM_TRY(plan_workspace(ctx, p, w, (size_t)L * L * 2 + (size_t)H * W, (size_t)H * W));
-  float* d_us = w.tmp1; float* d_v = w.tmp1 + (size_t)L * L; float* d_full = w.tmp1 + (size_t)2 * L * L;
-  std::vector<float> us((size_t)L * L), vv((size_t)L * L);
-  for (int r = 0; r < L; ++r)
-    for (int k = 0; k < L; ++k) us[(size_t)r * L + k] = Uw[(size_t)r * L + k] * sh[k];   // Uw is H x L, rows < L
-  for (int k = 0; k < L; ++k) memcpy(&vv[(size_t)k * L], &Vwt[(size_t)k * W], (size_t)L * 4);
-  WM_HIP(hipMemcpyAsync(d_us, us.data(), us.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  // tmp1: Uw[:L,:L] | Vwt[:L,:L] | Uw*sh | padded product;  tmp2: GEMM intermediate
+  WM_TRY(plan_workspace(ctx, p, w, (size_t)L * L * 3 + (size_t)H * W, (size_t)H * W));
+  float* d_u = w.tmp1; float* d_v = d_u + (size_t)L * L; float* d_us = d_v + (size_t)L * L;
+  float* d_full = d_us + (size_t)L * L;
+  std::vector<float> vv((size_t)L * L);
+  for (int k = 0; k < L; ++k) memcpy(&vv[(size_t)k * L], &Vwt[(size_t)k * W], (size_t)L * 4);      // Vwt[:L,:L]
+  WM_HIP(hipMemcpyAsync(d_u, Uw, (size_t)L * L * 4, hipMemcpyHostToDevice, ctx->stream));            // Uw[:L,:L] (H x L, rows < L)
   WM_HIP(hipMemcpyAsync(d_v, vv.data(), vv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  WM_HIP(hipMemsetAsync(d_full, 0, (size_t)H * W * 4, ctx->stream));            // single:215
-  WM_TRY(sgemm(ctx, false, false, L, L, L, 1.0f, d_us, L, d_v, L, 0.0f, d_full, W));   // single:216-217
   float *dH, *dW;
   WM_TRY(get_dct(ctx, H, 0, &dH));
   WM_TRY(get_dct(ctx, W, 1, &dW));
-  // idct2(X) = D_H^T X D_W                                                      single:218
-  WM_TRY(sgemm(ctx, true, false, H, W, H, 1.0f, dH, H, d_full, W, 0.0f, w.tmp2, W));
-  WM_TRY(sgemm(ctx, false, false, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_full, W));
-  WM_HIP(hipMemcpyAsync(out, d_full, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<float> sh((size_t)p.Lp, 0.0f);
+  for (int z = 0; z < n_planes; ++z) {
+    std::fill(sh.begin(), sh.end(), 0.0f);
+    for (int i = 0; i < K; ++i) sh[i] = (s_cw[(size_t)z * L + i] - sigma_c[(size_t)z * L + i]) / a;   // single:212-213
+    WM_HIP(hipMemcpyAsync(w.dvec, sh.data(), (size_t)L * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));       // sh is reused by the next plane
+    // Uw[:L,:L] * sh (column scaling) == diag applied from the right:  (U diag(sh)) = (diag(sh) U^T)^T
+    hipLaunchKernelGGL(k_rf_scale_cols, dim3(8, L), dim3(256), 0, ctx->stream, d_u, d_us, L, w.dvec);
+    WM_HIP(hipMemsetAsync(d_full, 0, (size_t)H * W * 4, ctx->stream));                                // single:215
+    WM_TRY(sgemm(ctx, false, false, L, L, L, 1.0f, d_us, L, d_v, L, 0.0f, d_full, W));                // single:214, 216-217
+    WM_TRY(sgemm(ctx, true, false, H, W, H, 1.0f, dH, H, d_full, W, 0.0f, w.tmp2, W));                // idct2: D_H^T X
+    WM_TRY(sgemm(ctx, false, false, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_full, W));               //        ... D_W   single:218
+    WM_HIP(hipMemcpyAsync(out + (size_t)z * H * W, d_full, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw, const float* Vwt,
+                      float* out, int H, int W, int row_stride, float alpha, int K) {
+  return wm_ref_extract_planes_u8(ctx, stego, sigma_c, Uw, Vwt, out, 1, H, W, row_stride, (size_t)H * row_stride,
+                                  alpha, K);
+}
+
+// outer sweeps the last full-frame SVD on this context took (for flop accounting)
+int wm_ref_last_sweeps(wm_ctx* ctx, int* sweeps_out) {
+  if (!ctx || !sweeps_out) return set_err(WM_ERR_BADARG, "NULL argument");
+  *sweeps_out = ctx->ref_last_sweeps;
   return WM_OK;
 }
 

@@ -70,10 +70,12 @@ SIGNATURES = {
     "wm_detect_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f],
     "wm_ref_embed_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_sigma_u8": [_vp, _vp, _vp, _i, _i, _i],
+    "wm_ref_last_sweeps": [_vp, C.POINTER(_i)],
     "wm_ref_embed_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_ref_sigma_planes_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
     "wm_ref_svd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
+    "wm_ref_extract_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f, _i],
     "wm_ref_detect_u8": [_vp, _vp, _vp, _vp, C.POINTER(C.c_double), _i, _i, _i, _f],
     "wm_bgr_to_ycrcb_u8_dev": [_vp, _vp, _vp, _sz],
     "wm_ycrcb_to_bgr_u8_dev": [_vp, _vp, _vp, _sz],
@@ -377,6 +379,11 @@ class Context:
                    L if sw.ndim == 2 else 0, float(alpha), int(K))
         return stego, sc, yw
 
+    def ref_last_sweeps(self) -> int:
+        n = _i(0)
+        self._call("wm_ref_last_sweeps", C.byref(n))
+        return n.value
+
     def ref_sigma_planes(self, planes: np.ndarray) -> np.ndarray:
         if planes.dtype != np.uint8 or planes.ndim != 3:
             raise ValueError("planes must be uint8 [N, H, W]")
@@ -419,6 +426,22 @@ class Context:
         out = np.empty((H, W), np.float32)
         self._call("wm_ref_extract_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
                    _vp(Vwt.ctypes.data), _vp(out.ctypes.data), H, W, W, float(alpha), int(K))
+        return out
+
+    def ref_extract_planes(self, stegos: np.ndarray, sigma_c, Uw, Vwt, alpha: float, K: int) -> np.ndarray:
+        """stegos uint8 [n, H, W] sharing one watermark decomposition; sigma_c [n, L]."""
+        if stegos.dtype != np.uint8 or stegos.ndim != 3:
+            raise ValueError("stego planes must be uint8 [n, H, W]")
+        stegos = np.ascontiguousarray(stegos)
+        n, H, W = stegos.shape
+        L = min(H, W)
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32)
+        Uw = np.ascontiguousarray(Uw, dtype=np.float32); Vwt = np.ascontiguousarray(Vwt, dtype=np.float32)
+        if sc.shape != (n, L) or Uw.shape != (H, L) or Vwt.shape != (L, W):
+            raise ValueError("meta arrays do not match the plane size")
+        out = np.empty((n, H, W), np.float32)
+        self._call("wm_ref_extract_planes_u8", _vp(stegos.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
+                   _vp(Vwt.ctypes.data), _vp(out.ctypes.data), n, H, W, W, H * W, float(alpha), int(K))
         return out
 
     def ref_detect(self, stego: np.ndarray, sigma_c, sigma_w, alpha: float) -> float:

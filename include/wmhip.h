@@ -194,6 +194,16 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
 int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
                       const float* Vwt, float* out, int H, int W, int row_stride, float alpha, int K);
 
+/* The same for n_planes stego planes that share ONE watermark decomposition (the frames
+ * of a clip, single:205-218 applied per frame): their SVDs run as one batch.
+ *   sigma_c [n_planes][L], out [n_planes][H][W] float32. */
+int wm_ref_extract_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                             const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                             size_t plane_stride, float alpha, int K);
+
+/* Diagnostics: outer Jacobi sweeps the last full-frame SVD on this context needed. */
+int wm_ref_last_sweeps(wm_ctx* ctx, int* sweeps_out);
+
 /* Replaces single:297-301 + _nc (single:284-289): score over all L singular values. */
 int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
                      double* score, int H, int W, int row_stride, float alpha);

@@ -56,6 +56,26 @@ def test_fullframe_watermark_svd_and_extract(gpu_ctx, H, W):
     assert np.corrcoef(w2[:hh, :hh].ravel(), wo[:hh, :hh].ravel())[0, 1] > 0.98
 
 
+def test_fullframe_batched_extract_equals_single(gpu_ctx):
+    """Frames of a clip share the watermark factors: one batched call == per-frame calls."""
+    H, W, alpha = 96, 128, 0.15
+    rng = np.random.default_rng(5)
+    hosts = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+    U, S, Vt = gpu_ctx.ref_svd(wys, apply_dct=True)
+    K = 57
+    st, sc, _ = gpu_ctx.ref_embed_planes(hosts, S, alpha, K)
+    wb = gpu_ctx.ref_extract_planes(st, sc, U, Vt, alpha, K)
+    assert wb.shape == (3, H, W)
+    for p in range(3):
+        w1 = gpu_ctx.ref_extract(st[p], sc[p], U, Vt, alpha, K)
+        assert np.abs(wb[p] - w1).max() <= 2e-3 * np.abs(w1).max()
+        wo = o.extract_plane(st[p].astype(np.float32), sc[p], U, Vt, alpha, 0.6, H, W, None)
+        assert np.abs(wb[p] - wo).max() < 5e-3 * np.abs(wo).max()
+    with pytest.raises(ValueError):
+        gpu_ctx.ref_extract_planes(st, sc[:2], U, Vt, alpha, K)
+
+
 def test_fullframe_batched_planes_equal_single(gpu_ctx):
     """B,G,R planes / frames through one set of launches (grid.z = plane): same results
     as plane-by-plane, with per-plane or shared watermark sigma."""
