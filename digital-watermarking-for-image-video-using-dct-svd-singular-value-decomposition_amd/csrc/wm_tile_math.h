@@ -141,6 +141,13 @@ WM_HD void idct8x8(float (&a)[8][8]) {
 constexpr float JAC_TOL2 = 1e-15f;   // skip a rotation below cos = 3.2e-8
 constexpr float JAC_CONV2 = 1e-7f;   // "converged" sweep: max cos < 3.2e-4
 constexpr int JAC_MAX_SWEEPS = 12;
+// Singular VALUES alone converge one order ahead of the vectors: after a sweep that saw
+// max cos c the columns are orthogonal to ~c^2 and |b_i| = s_i (1 + O(c^4)), so the
+// sigma-only kernels (extract, detect, K2) may stop at c < 3.2e-2 - their sigma error
+// stays at the float32 rounding floor (tools/conv_study.cpp: 8.6e-7 s_1 for every
+// threshold from 1e-7 to 1e-3) with 4.1 instead of 5.0 sweeps per wave.  The embed keeps
+// JAC_CONV2: its reconstruction needs the VECTORS (B orthogonal to 1e-7).
+constexpr float JAC_CONV2_SIGMA = 1e-3f;
 
 template <bool WITH_V>
 WM_HD void jacobi_rot(float (&a)[8][8], float (&v)[8][8], float (&n2)[8],
@@ -254,14 +261,15 @@ constexpr float SIGMA_RATIO_MIN2 = 1e-10f;   // (s_8 / s_1)^2 below this -> lite
 
 // one Jacobi rotation of columns p,q (no V).  c0 = cos, s0 = sin*sign(g) from
 // two v_rsq_f32:  cos^2 = (1 + |tau|/h)/2,  sin = g / (h cos),  h^2 = tau^2+4g^2.
-template <bool CHECK>
+// CHECK: 0 = no convergence test, 1 = JAC_CONV2 (vectors needed), 2 = JAC_CONV2_SIGMA.
+template <int CHECK>
 WM_HD void jacobi_rot_pk(v2f (&a)[4][8], float (&n2)[8], const int p, const int q, bool& notconv) {
   v2f gv = a[0][p] * a[0][q];
 #pragma unroll
   for (int rp = 1; rp < 4; ++rp) gv = fma2(a[rp][p], a[rp][q], gv);
   const float g = gv[0] + gv[1];
   const float al = n2[p], be = n2[q];
-  if (CHECK) notconv = notconv || (g * g > JAC_CONV2 * (al * be));
+  if (CHECK) notconv = notconv || (g * g > (CHECK == 2 ? JAC_CONV2_SIGMA : JAC_CONV2) * (al * be));
   const float tau = be - al;
   const float ta = fabsf(tau) + 1e-18f;          // keeps 0/0 out: g == 0 -> cos = 1 exactly
   const float g2 = g + g;
@@ -296,7 +304,7 @@ WM_HD void col_norms2_pk(const v2f (&a)[4][8], float (&n2)[8]) {
 
 // B = X V with orthogonal columns sorted by norm; n2 = |b_i|^2.  Returns the
 // sweep count (negative: bound hit).
-template <bool CHECK>
+template <int CHECK>
 WM_HD void jacobi_sweep_pk(v2f (&a)[4][8], float (&n2)[8], bool& notconv) {
 #pragma unroll
   for (int p = 0; p < 7; ++p)
@@ -304,6 +312,7 @@ WM_HD void jacobi_sweep_pk(v2f (&a)[4][8], float (&n2)[8], bool& notconv) {
     for (int q = p + 1; q < 8; ++q) jacobi_rot_pk<CHECK>(a, n2, p, q, notconv);
 }
 
+template <bool SIGMA_ONLY = false>
 WM_HD int jacobi_cols_pk(v2f (&a)[4][8], float (&n2)[8]) {
   // Sweeps 1 and 2 carry no convergence test (a sweep can only be the last one if
   // it tested every pair, so these two are never last; on image tiles the earliest
@@ -311,14 +320,14 @@ WM_HD int jacobi_cols_pk(v2f (&a)[4][8], float (&n2)[8]) {
   // tracked through the even ones.
   bool notconv = false;
   col_norms2_pk(a, n2);
-  jacobi_sweep_pk<false>(a, n2, notconv);
-  jacobi_sweep_pk<false>(a, n2, notconv);
+  jacobi_sweep_pk<0>(a, n2, notconv);
+  jacobi_sweep_pk<0>(a, n2, notconv);
   int sweep = 2;
   bool more = true;
   while (more && sweep < JAC_MAX_SWEEPS) {
     if ((sweep & 1) == 0) col_norms2_pk(a, n2);
     notconv = false;
-    jacobi_sweep_pk<true>(a, n2, notconv);
+    jacobi_sweep_pk<SIGMA_ONLY ? 2 : 1>(a, n2, notconv);
     ++sweep;
     more = wave_any(notconv);
   }
@@ -354,7 +363,7 @@ WM_HD int sigma_tile_pk(const RawTile& t, float (&s)[8]) {
   v2f a[4][8];
   float n2[8];
   raw_to_pk(t, a);
-  const int sweeps = jacobi_cols_pk(a, n2);
+  const int sweeps = jacobi_cols_pk<true>(a, n2);
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = fsqrt(n2[i]);
   return sweeps;
