@@ -518,42 +518,113 @@ WM_HD void add_completion(float (&a)[8][8], const float scale) {
     for (int c = 0; c < 8; ++c) a[r][c] = ffma(scale, COMPLETION_PATTERN[r][c], a[r][c]);
 }
 
+// ---- packed one-sided Jacobi WITH V: A and V stacked as one 16-row matrix ----
+// The same rotation (jacobi_rot_pk's two-rsq angle) is applied to the 4 row pairs
+// of A and the 4 row pairs of V; dot products and norms come from the A half only.
+template <int CHECK>
+WM_HD void jacobi_rot_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], const int p, const int q,
+                           bool& notconv) {
+  v2f gv = a[0][p] * a[0][q];
+#pragma unroll
+  for (int rp = 1; rp < 4; ++rp) gv = fma2(a[rp][p], a[rp][q], gv);
+  const float g = gv[0] + gv[1];
+  const float al = n2[p], be = n2[q];
+  if (CHECK) notconv = notconv || (g * g > JAC_CONV2 * (al * be));
+  const float tau = be - al;
+  const float ta = fabsf(tau) + 1e-18f;
+  const float g2 = g + g;
+  const float ih = frsq(ffma(g2, g2, ta * ta));
+  const float x = ffma(0.5f * ta, ih, 0.5f);
+  const float rx = frsq(x);
+  const float c0 = x * rx;
+  const float s0 = (g * ih) * rx;
+  const bool sw = tau > 0.0f;
+  const float C = sw ? s0 : c0, Sn = sw ? c0 : s0;
+  const float w = fabsf((s0 * rx) * g);
+  n2[p] = fmaxf(al, be) + w;
+  n2[q] = fminf(al, be) - w;
+  const v2f Cv = splat2(C), Sv = splat2(Sn);
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp) {
+    const v2f X = a[rp][p], Y = a[rp][q];
+    a[rp][p] = fma2(Cv, X, Sv * Y);
+    a[rp][q] = fma2(Cv, Y, -(Sv * X));
+  }
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp) {
+    const v2f X = v[rp][p], Y = v[rp][q];
+    v[rp][p] = fma2(Cv, X, Sv * Y);
+    v[rp][q] = fma2(Cv, Y, -(Sv * X));
+  }
+}
+
+// B = A V (columns orthogonal, sorted by norm), V accumulated from the identity.
+// n2 = |b_i|^2, vn2 = |v_i|^2 (1 up to the drift of v_rsq_f32, carried so that it
+// cancels in sigma_i = |b_i| / |v_i|).  Column norms are recomputed before every
+// sweep: this is the path for tiles whose trailing columns are ~1e-8 of the leading one.
+WM_HD int jacobi_cols_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], float (&vn2)[8]) {
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v2f e = {(2 * rp == c) ? 1.0f : 0.0f, (2 * rp + 1 == c) ? 1.0f : 0.0f};
+      v[rp][c] = e;
+    }
+  int sweep = 0;
+  bool more = true;
+  while (more && sweep < JAC_MAX_SWEEPS) {
+    col_norms2_pk(a, n2);
+    bool notconv = false;
+#pragma unroll
+    for (int p = 0; p < 7; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 8; ++q) jacobi_rot_pk_v<1>(a, v, n2, p, q, notconv);
+    ++sweep;
+    more = wave_any(notconv);
+  }
+  col_norms2_pk(a, n2);
+  col_norms2_pk(v, vn2);
+  return more ? -sweep : sweep;
+}
+
 // literal chain on a (possibly) rank-deficient tile: dct2 -> (+delta P) -> svd
 // with V -> U diag(S + alpha Sw) V^T -> (-delta P) -> idct2
 WM_HD int embed_tile_completed(float (&a)[8][8], const float (&sw)[8], const float (&alpha_k)[8],
                                float (&sc)[8]) {
-  float v[8][8], n2[8], vn2[8];
   dct8x8(a);
   add_completion(a, COMPLETION_DELTA);
-  const int sweeps = jacobi_svd8<true>(a, v, n2, vn2);
-  float f[8];
+  v2f b[4][8], v[4][8];
+  float n2[8], vn2[8];
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v2f t = {a[2 * rp][c], a[2 * rp + 1][c]};
+      b[rp][c] = t;
+    }
+  const int sweeps = jacobi_cols_pk_v(b, v, n2, vn2);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float nb = fsqrt(n2[i]), nv = fsqrt(vn2[i]);
-    const float sig = nb * frcp(nv);
+    const float sig = nb * frcp(nv);                      // sigma_i = |b_i| / |v_i|
     sc[i] = sig;
-    const float sp = ffma(alpha_k[i], sw[i], sig);
+    const float sp = ffma(alpha_k[i], sw[i], sig);        // S_[:K] = Sc[:K] + alpha*Sw[:K]
     const float den = nb * nv;
-    f[i] = (den > 0.0f) ? sp * frcp(den) : 0.0f;
+    const float f = (den > 0.0f) ? sp * frcp(den) : 0.0f; // sigma'_i / (|b_i| |v_i|)
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp) b[rp][i] = b[rp][i] * splat2(f);
   }
-  float cw[8][8];
+  // Cw = sum_i (b_i f_i) v_i^T   ==  U diag(S_) V^T ; row pair rp, column c
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    float bs[8];
+  for (int c = 0; c < 8; ++c)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bs[i] = a[r][i] * f[i];
+    for (int rp = 0; rp < 4; ++rp) {
+      v2f acc = b[rp][0] * splat2(v[c >> 1][0][c & 1]);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float s = bs[0] * v[c][0];
-#pragma unroll
-      for (int i = 1; i < 8; ++i) s = ffma(bs[i], v[c][i], s);
-      cw[r][c] = s;
+      for (int i = 1; i < 8; ++i) acc = fma2(b[rp][i], splat2(v[c >> 1][i][c & 1]), acc);
+      a[2 * rp][c] = acc[0];
+      a[2 * rp + 1][c] = acc[1];
     }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) a[r][c] = cw[r][c];
   add_completion(a, -COMPLETION_DELTA);
   idct8x8(a);
   return sweeps;
