@@ -248,28 +248,61 @@ __device__ __forceinline__ float ord2f(unsigned o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// min/max in two stages without atomics: each block leaves one {lo, hi} pair in
+// mm[2*block ..]; the consumer (k_normalize_u8) folds the n_part pairs again per block.
+constexpr unsigned MINMAX_BLOCKS = 512;
+
+__device__ __forceinline__ void block_minmax(unsigned& lo, unsigned& hi) {
+  __shared__ unsigned s_lo[4], s_hi[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_down(lo, o, 64)); hi = max(hi, __shfl_down(hi, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+  hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+}
+
 __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ x, const size_t n, unsigned* __restrict__ mm) {
   unsigned lo = 0xffffffffu, hi = 0u;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  const size_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);          // hipMalloc'd planes are 16-byte aligned (checked on the host)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    const unsigned a = f2ord(v.x), b = f2ord(v.y), c = f2ord(v.z), d = f2ord(v.w);
+    lo = min(min(lo, a), min(b, min(c, d))); hi = max(max(hi, a), max(b, max(c, d)));
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const unsigned o = f2ord(x[i]);
     lo = min(lo, o); hi = max(hi, o);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_down(lo, o, 64)); hi = max(hi, __shfl_down(hi, o, 64)); }
-  if ((threadIdx.x & 63) == 0) { atomicMin(mm, lo); atomicMax(mm + 1, hi); }
+  block_minmax(lo, hi);
+  if (threadIdx.x == 0) { mm[2 * blockIdx.x] = lo; mm[2 * blockIdx.x + 1] = hi; }
 }
 
 __global__ __launch_bounds__(256) void k_normalize_u8(const float* __restrict__ x, const size_t n,
-                                                     const unsigned* __restrict__ mm, const int do_norm,
-                                                     uint8_t* __restrict__ out) {
-  const float lo = ord2f(mm[0]), hi = ord2f(mm[1]);
-  const double range = (double)hi - (double)lo;
-  const float scale = (range > 2.220446049250313e-16) ? (float)(255.0 / range) : 0.0f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float v = x[i];
-    if (do_norm) v = (v - lo) * scale;
-    out[i] = (uint8_t)(unsigned)fminf(fmaxf(v, 0.0f), 255.0f);
+                                                     const unsigned* __restrict__ mm, const unsigned n_part,
+                                                     const int do_norm, uint8_t* __restrict__ out) {
+  unsigned ulo = 0xffffffffu, uhi = 0u;
+  if (do_norm) {
+    for (unsigned i = threadIdx.x; i < n_part; i += blockDim.x) { ulo = min(ulo, mm[2 * i]); uhi = max(uhi, mm[2 * i + 1]); }
+    block_minmax(ulo, uhi);
   }
+  const float lo = ord2f(ulo), hi = ord2f(uhi);
+  const double range = (double)hi - (double)lo;
+  const float scale = (do_norm && range > 2.220446049250313e-16) ? (float)(255.0 / range) : 0.0f;
+  const auto q = [&](float v) -> unsigned {
+    if (do_norm) v = (v - lo) * scale;
+    return (unsigned)fminf(fmaxf(v, 0.0f), 255.0f);
+  };
+  const size_t n4 = (((uintptr_t)out & 3u) == 0) ? n / 4 : 0;     // 4 pixels per thread: one 16-byte load, one 4-byte store
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  unsigned* out4 = reinterpret_cast<unsigned*>(out);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    out4[i] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (uint8_t)q(x[i]);
 }
 
 inline unsigned grid_for(size_t work_items, unsigned block = 256, unsigned cap = 256 * 8) {
@@ -366,12 +399,12 @@ int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint
   if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
   if (n == 0) return WM_OK;
   if (!x || !out) return set_err(WM_ERR_BADARG, "NULL argument");
-  WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, 64, "minmax"));
-  unsigned* mm = (unsigned*)ctx->partials;       // {min, max} in order-preserving uint form
-  WM_HIP(hipMemsetAsync(mm, 0xff, sizeof(unsigned), ctx->stream));
-  WM_HIP(hipMemsetAsync(mm + 1, 0x00, sizeof(unsigned), ctx->stream));
-  if (do_norm) hipLaunchKernelGGL(k_minmax, dim3(grid_for(n)), dim3(256), 0, ctx->stream, x, n, mm);
-  hipLaunchKernelGGL(k_normalize_u8, dim3(grid_for(n)), dim3(256), 0, ctx->stream, x, n, mm, do_norm, out);
+  if (((uintptr_t)x & 15u) != 0) return set_err(WM_ERR_BADARG, "float plane must be 16-byte aligned");
+  WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, MINMAX_BLOCKS * 2 * sizeof(unsigned), "minmax"));
+  unsigned* mm = (unsigned*)ctx->partials;       // per-block {min, max} in order-preserving uint form
+  const unsigned n_part = grid_for(n / 4 + 1, 256, MINMAX_BLOCKS);
+  if (do_norm) hipLaunchKernelGGL(k_minmax, dim3(n_part), dim3(256), 0, ctx->stream, x, n, mm);
+  hipLaunchKernelGGL(k_normalize_u8, dim3(grid_for(n / 4 + 1)), dim3(256), 0, ctx->stream, x, n, mm, n_part, do_norm, out);
   WM_HIP(hipGetLastError());
   return WM_OK;
 }

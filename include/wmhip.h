@@ -228,7 +228,8 @@ int wm_sqdiff_u8_dev(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, 
  * strides in elements; kind bit0 / bit1: img1 / img2 is float32 instead of uint8 */
 int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2, size_t stride2,
                 int H, int W, int kind, double* ssim_dev);
-/* uint8(clip(cv2.normalize(x, 0, 255, NORM_MINMAX), 0, 255))  (single:221-222); do_norm=0: clip only */
+/* uint8(clip(cv2.normalize(x, 0, 255, NORM_MINMAX), 0, 255))  (single:221-222); do_norm=0: clip only.
+ * x must be 16-byte aligned (any wm_malloc'd plane is). */
 int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint8_t* out);
 /* host-pointer conveniences; op: 0 BGR->YCrCb, 1 YCrCb->BGR, 2 BGR->gray plane, 3 BGR->Y plane,
  * 4 replace Y (plane_in) and return BGR */
