@@ -643,19 +643,31 @@ WM_HD int sigma_tile(float (&a)[8][8], float (&s)[8]) {
 // ---- full SVD of a float tile (watermark side): U, S, Vt --------------------
 // u[r][i], vt[i][c]; columns with sigma == 0 get u_i = 0.
 WM_HD int svd_tile(float (&a)[8][8], float (&s)[8], float (&vt)[8][8], const bool complete = false) {
-  float v[8][8], n2[8], vn2[8];
   dct8x8(a);
   if (complete) add_completion(a, COMPLETION_DELTA);
-  const int sweeps = jacobi_svd8<true>(a, v, n2, vn2);
+  v2f b[4][8], v[4][8];
+  float n2[8], vn2[8];
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v2f t = {a[2 * rp][c], a[2 * rp + 1][c]};
+      b[rp][c] = t;
+    }
+  const int sweeps = jacobi_cols_pk_v(b, v, n2, vn2);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float rb = (n2[i] > 0.0f) ? frsq(n2[i]) : 0.0f;
     const float rv = frsq(vn2[i]);
     s[i] = fsqrt(n2[i]) * rv;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a[r][i] *= rb;            // U = B / |b_i|
+    for (int rp = 0; rp < 4; ++rp) {                      // U = B / |b_i|
+      const v2f u = b[rp][i] * splat2(rb);
+      a[2 * rp][i] = u[0];
+      a[2 * rp + 1][i] = u[1];
+    }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) vt[i][c] = v[c][i] * rv;  // Vt = (V / |v_i|)^T
+    for (int c = 0; c < 8; ++c) vt[i][c] = v[c >> 1][i][c & 1] * rv;   // Vt = (V / |v_i|)^T
   }
   return sweeps;
 }

@@ -330,28 +330,26 @@ __global__ __launch_bounds__(WAVE, 2) void k_svd_tiles(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 8; ++r) load_row8_f32<VECF>(p + (size_t)r * g.row_stride, a[r]);
   if (wm::svd_tile(a, s, vt) < 0) atomicOr(status, 1);
-  // rank-deficient watermark tiles: redo with the completion pattern so that Uw
-  // stays a full orthonormal basis (rare: wave-uniform branch)
+  const size_t ti = plane * g.n_tiles + t;
   const bool deficient = !(s[7] > 1e-5f * s[0]);
+  if (!deficient) {
+    store_row8_f32<true>(S + ti * 8, s);
+    store_mat_f32(U + ti * 64, a);
+    store_mat_f32(Vt + ti * 64, vt);
+  }
+  // rank-deficient watermark tiles: redo with the completion pattern so that Uw
+  // stays a full orthonormal basis (rare: wave-uniform branch, nothing kept live across it)
   if (wm::wave_any(deficient)) {
-    float a2[8][8], s2[8], vt2[8][8];
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int r = 0; r < 8; ++r) load_row8_f32<VECF>(p + (size_t)r * g.row_stride, a2[r]);
-    if (wm::svd_tile(a2, s2, vt2, true) < 0) atomicOr(status, 1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      s[r] = deficient ? s2[r] : s[r];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        a[r][c] = deficient ? a2[r][c] : a[r][c];
-        vt[r][c] = deficient ? vt2[r][c] : vt[r][c];
-      }
+    for (int r = 0; r < 8; ++r) load_row8_f32<VECF>(p + (size_t)r * g.row_stride, a[r]);
+    if (wm::svd_tile(a, s, vt, true) < 0) atomicOr(status, 1);
+    if (deficient) {
+      store_row8_f32<true>(S + ti * 8, s);
+      store_mat_f32(U + ti * 64, a);
+      store_mat_f32(Vt + ti * 64, vt);
     }
   }
-  const size_t ti = plane * g.n_tiles + t;
-  store_row8_f32<true>(S + ti * 8, s);
-  store_mat_f32(U + ti * 64, a);
-  store_mat_f32(Vt + ti * 64, vt);
 }
 
 // ---------------------------------------------------------------------------
