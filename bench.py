@@ -114,7 +114,7 @@ def main_fullframe(a):
         st, sc, sweeps = step()
     dt = time.perf_counter() - t0
     Lp = (L + 63) // 64 * 64; M = max(H, W); nbk = Lp // 32
-    flops_sweep = (nbk - 1) * (nbk // 2) * (2.0 * 64 * 64 * M + 2.0 * 64 * 64 * (M + Lp))
+    flops_sweep = (nbk - 1) * (nbk // 2) * (2.0 * 64 * 64 * M + 2.0 * 64 * 64 * M)   # gram + apply on the M columns (no [A | I] block)
     t_embed0 = time.perf_counter(); ctx.ref_embed_planes(frames, Sw, alpha, K); t_embed = time.perf_counter() - t_embed0
     achieved = flops_sweep * ctx.ref_last_sweeps() * F / t_embed / 1e12
     t1 = time.perf_counter(); c0 = time.process_time()
@@ -131,7 +131,8 @@ def main_fullframe(a):
                       "frames_per_rank": F, "height": H, "width": W},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                         "traffic": None, "kernel": "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)",
-                        "note": f"{ctx.ref_last_sweeps()} sweeps; latency-bound small launches, float32 (MFMA f32 rate = VALU rate)"},
+                        "note": f"{ctx.ref_last_sweeps()} sweeps; each step also moves 3 x planes x Lp x M x 4 B (gram read, apply read+write) "
+                                f"and waits ~35 us on the per-pair inner solve, float32 (MFMA f32 rate = VALU rate)"},
            "cpu_baseline": {"value": 1.0 / wall, "unit": "frames/s", "cores": int(cores), "kind": "port",
                             "sample": f"1 frame {W}x{H}: NumPy/LAPACK oracle embed (incl. its watermark SVD) + extract",
                             "host_cpus": os.cpu_count()},

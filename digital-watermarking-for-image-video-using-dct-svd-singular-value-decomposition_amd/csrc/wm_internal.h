@@ -44,6 +44,8 @@ struct wm_ctx {
   float* dct_mat[2] = {nullptr, nullptr};   // cached DCT-II basis matrices (device), by size
   int dct_n[2] = {0, 0};
   int ref_last_sweeps = 0;        // outer Jacobi sweeps of the last full-frame SVD (diagnostics)
+  hipStream_t aux_stream = nullptr;   // second queue of the batched full-frame Jacobi (created on first use)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[wmi::N_EVENTS] = {};
 };
 

@@ -36,6 +36,10 @@ constexpr int GRAM_CC = 128;  // columns per Gram partial
 constexpr int MAX_SWEEPS = 40;
 constexpr int FULL_INNER_SWEEPS = 0;   // outer sweeps whose every step runs the full 63-step inner schedule
 constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to ~eps*sqrt(M)
+// sigma-only calls (extract, detect): row norms are exact to O(cos^2), and the sweep that
+// observes max cos < c still rotates (leaving ~c^2), so they may stop an order earlier (2e-3 already costs 7e-5 relative on dense spectra: tools/ff_sigma_thr.py)
+constexpr float CONV_COS_SIGMA = 2e-4f;
+constexpr double NULL_RATIO = 1e-6;   // embed: singular directions below this fraction of s_1 get no watermark energy
 
 // ---------------------------------------------------------------------------
 // generic row-major SGEMM:  C = alpha * op(A) op(B) + beta * C
@@ -189,43 +193,54 @@ __device__ __forceinline__ int rr_elem(const int pos, const int step) {
 // (bipartite schedule, 32 steps); the within-block pairs are covered once per
 // outer sweep by the full 63-step schedule (every block sits in exactly one
 // pair of the sweep's first step).
-__global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ partials, const int nch,
-                                                 float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits,
-                                                 const int cross_only) {
+constexpr int INNER_NT = 1024;                 // threads per workgroup: one 2x2 block of G per thread
+constexpr int INNER_NW = INNER_NT / 64;
+
+__global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__ partials, const int nch,
+                                                      float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits,
+                                                      const int cross_only) {
   __shared__ float GG[2][RP][RP + 1];   // double-buffered: a step reads one copy, writes the other
   float (*G)[RP + 1] = GG[0];
   __shared__ float R[RP][RP + 1];
-  __shared__ float WCs[4][32], WSs[4][32];
-  __shared__ int WPs[4][32], WQs[4][32];
-  __shared__ float red[4];
+  __shared__ float WCs[INNER_NW][32], WSs[INNER_NW][32];
+  __shared__ int WPs[INNER_NW][32], WQs[INNER_NW][32];
+  __shared__ float red[INNER_NW];
   const int t = threadIdx.x, p = blockIdx.x;
   partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
   Rout += (size_t)blockIdx.z * gridDim.x * RP * RP;
   maxcos_bits += blockIdx.z;
   const float* src = partials + (size_t)p * nch * RP * RP;
   {
-    // sum the column-chunk partials: 16 independent loads in flight per chunk
-    float acc[16];
+    // sum the column-chunk partials: independent loads in flight (4 elements x 4 chunks)
+    constexpr int PER = RP * RP / INNER_NT;
+    float acc[PER];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    for (int ch = 0; ch < nch; ++ch) {
-      const float* pc = src + (size_t)ch * RP * RP + t;
-      float v[16];
+    for (int i = 0; i < PER; ++i) acc[i] = 0.0f;
+    int ch = 0;
+    for (; ch + 4 <= nch; ch += 4) {
+      float v[4][PER];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = pc[256 * i];
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] += v[i];
+        for (int i = 0; i < PER; ++i) v[u][i] = src[(size_t)(ch + u) * RP * RP + t + INNER_NT * i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] += v[u][i];
     }
+    for (; ch < nch; ++ch)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = t + 256 * i;
+      for (int i = 0; i < PER; ++i) acc[i] += src[(size_t)ch * RP * RP + t + INNER_NT * i];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = t + INNER_NT * i;
       G[e >> 6][e & 63] = acc[i];
       R[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0f : 0.0f;
     }
   }
   __syncthreads();
   float mx = 0.0f;
-  for (int e = t; e < RP * RP; e += 256) {
+  for (int e = t; e < RP * RP; e += INNER_NT) {
     const int r = e >> 6, c = e & 63;
     if (r != c) {
       const float d = G[r][r] * G[c][c];
@@ -236,13 +251,18 @@ __global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ part
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
   if ((t & 63) == 0) red[t >> 6] = mx;
   __syncthreads();
-  if (t == 0) atomicMax(maxcos_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  if (t == 0) {
+    float m = red[0];
+#pragma unroll
+    for (int i = 1; i < INNER_NW; ++i) m = fmaxf(m, red[i]);
+    atomicMax(maxcos_bits, __float_as_uint(m));
+  }
 
-  // thread -> four 2x2 blocks (k1, k2) of G and eight (row, pair) items of R.
+  // thread -> one 2x2 block (k1, k2) of G and two (row, pair) items of R.
   // Every wave computes all 32 rotations of the step redundantly (lanes 0..31)
   // into its own LDS slice, so a step needs ONE workgroup barrier (after the
   // updates) instead of two.
-  const int k1 = t >> 3, k2b = (t & 7) * 4;
+  const int k1 = t >> 5, k2 = t & 31;
   const int wv = t >> 6, lane = t & 63;
   float* Cw = &WCs[wv][0]; float* Sw_ = &WSs[wv][0];
   int* Pw = &WPs[wv][0]; int* Qw = &WQs[wv][0];
@@ -270,39 +290,30 @@ __global__ __launch_bounds__(256) void k_rf_inner(const float* __restrict__ part
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     float (*Gn)[RP + 1] = GG[(step + 1) & 1];
-    // G <- J^T G J, one 2x2 block (rows of pair k1, columns of pair k2) at a time
+    // G <- J^T G J on the 2x2 block (rows of pair k1, columns of pair k2)
     {
       const int p1 = Pw[k1], q1 = Qw[k1];
       const float C1 = Cw[k1], S1 = Sw_[k1];
+      const int p2 = Pw[k2], q2 = Qw[k2];
+      const float C2 = Cw[k2], S2 = Sw_[k2];
+      const float gpp = G[p1][p2], gpq = G[p1][q2], gqp = G[q1][p2], gqq = G[q1][q2];
+      const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;   // row p1, columns rotated
+      const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;   // row q1
+      Gn[p1][p2] = C1 * a0 - S1 * b0; Gn[p1][q2] = C1 * a1 - S1 * b1;    // rows rotated
+      Gn[q1][p2] = S1 * a0 + C1 * b0; Gn[q1][q2] = S1 * a1 + C1 * b1;
+      // R <- R J : rows k1 and k1 + 32, column pair k2
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k2 = k2b + j;
-        const int p2 = Pw[k2], q2 = Qw[k2];
-        const float C2 = Cw[k2], S2 = Sw_[k2];
-        const float gpp = G[p1][p2], gpq = G[p1][q2], gqp = G[q1][p2], gqq = G[q1][q2];
-        const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;   // row p1, columns rotated
-        const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;   // row q1
-        Gn[p1][p2] = C1 * a0 - S1 * b0; Gn[p1][q2] = C1 * a1 - S1 * b1;    // rows rotated
-        Gn[q1][p2] = S1 * a0 + C1 * b0; Gn[q1][q2] = S1 * a1 + C1 * b1;
-      }
-    }
-    // R <- R J
-    {
-      const int k = t & 31;
-      const int pp = Pw[k], qq = Qw[k];
-      const float C = Cw[k], S = Sw_[k];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = (t >> 5) + 8 * i;
-        const float rp = R[r][pp], rq = R[r][qq];
-        R[r][pp] = C * rp - S * rq; R[r][qq] = S * rp + C * rq;
+      for (int i = 0; i < 2; ++i) {
+        const int r = k1 + 32 * i;
+        const float rp = R[r][p2], rq = R[r][q2];
+        R[r][p2] = C2 * rp - S2 * rq; R[r][q2] = S2 * rp + C2 * rq;
       }
     }
     __syncthreads();
     G = Gn;
   }
   float* out = Rout + (size_t)p * RP * RP;
-  for (int e = t; e < RP * RP; e += 256) out[e] = R[e >> 6][e & 63];
+  for (int e = t; e < RP * RP; e += INNER_NT) out[e] = R[e >> 6][e & 63];
 }
 
 // ---------------------------------------------------------------------------
@@ -373,6 +384,20 @@ __global__ __launch_bounds__(256) void k_rf_rownorms(const float* __restrict__ a
     b2[i] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     q2[i] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
+}
+
+// t2[i] = sum_j T[j][i]^2 (float64) of the dense [rows x cols] matrix T of every plane
+__global__ __launch_bounds__(256) void k_rf_colnorms(const float* __restrict__ T, const size_t plane_stride,
+                                                    const int rows, const int cols, double* __restrict__ t2) {
+  __shared__ double red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rs = threadIdx.x >> 6;
+  T += (size_t)blockIdx.y * plane_stride;
+  double acc = 0.0;
+  if (c < cols)
+    for (int j = rs; j < rows; j += 4) { const double v = (double)T[(size_t)j * cols + c]; acc += v * v; }
+  red[rs][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rs == 0 && c < cols) t2[(size_t)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // rows of the B part scaled in place:  B[i][:] *= d[i]
@@ -508,30 +533,66 @@ int get_dct(wm_ctx* ctx, int n, int slot, float** out) {
 }
 
 // block one-sided Jacobi on the B Aug matrices (already loaded); every launch covers
-// all planes (grid.z), sweeps continue until every plane's Gram matrices are diagonal
-// to CONV_COS.  sweeps_out: sweeps used (negative: bound hit).
+// a group of planes (grid.z), sweeps continue until every plane's Gram matrices are
+// diagonal to CONV_COS.  sweeps_out: sweeps used (negative: bound hit).
+//
+// A step is gram -> inner -> apply, and k_rf_inner is one latency-bound workgroup per
+// block pair (~35 us with most of the chip idle).  With two or more planes the batch is
+// split into two groups on two HIP streams, the second started one gram later, so one
+// group's inner solve runs under the other group's gram/apply tiles.
 int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int* sweeps_out) {
   const int ncols = with_q ? p.M + p.Lp : p.M;
   int sweep = 0;
   bool done = false;
   std::vector<unsigned> bits(p.B);
   static const int full_sweeps = getenv("WM_RF_FULL_SWEEPS") ? atoi(getenv("WM_RF_FULL_SWEEPS")) : FULL_INNER_SWEEPS;
+  static const bool two_queues = !(getenv("WM_RF_ONE_QUEUE") && atoi(getenv("WM_RF_ONE_QUEUE")));
+  static const float conv_sigma = getenv("WM_RF_CONV_SIGMA") ? (float)atof(getenv("WM_RF_CONV_SIGMA")) : CONV_COS_SIGMA;
+  const float conv_cos = with_q ? CONV_COS : conv_sigma;
+  const int B0 = (p.B >= 2 && two_queues) ? (p.B + 1) / 2 : p.B, B1 = p.B - B0;
+  if (B1 > 0 && !ctx->aux_stream) {
+    WM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    WM_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    WM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  const size_t par_ps = (size_t)p.npairs * p.nch * RP * RP, r_ps = (size_t)p.npairs * RP * RP;
+  auto step = [&](hipStream_t st, int z0, int nz, int s, int part) {
+    const int2* pr = w.pairs + (size_t)s * p.npairs;
+    float* aug = w.aug + (size_t)z0 * p.aug_ps;
+    float* par = w.partials + (size_t)z0 * par_ps;
+    float* R = w.R + (size_t)z0 * r_ps;
+    if (part & 1)
+      hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch, nz), dim3(256), 0, st, aug, p.aug_ps, p.ld, p.M, pr, par);
+    if (part & 2) {
+      hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
+                         (s == 0 || sweep < full_sweeps) ? 0 : 1);
+      hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (ncols + 63) / 64, nz), dim3(256), 0, st, aug, p.aug_ps, p.ld,
+                         ncols, pr, R);
+    }
+  };
   while (!done && sweep < MAX_SWEEPS) {
     WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));
-    for (int s = 0; s < p.nsteps; ++s) {
-      const int2* pr = w.pairs + (size_t)s * p.npairs;
-      hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, pr, w.partials);
-      hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, p.B), dim3(256), 0, ctx->stream, w.partials, p.nch, w.R, w.maxcos,
-                         (s == 0 || sweep < full_sweeps) ? 0 : 1);
-      hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (ncols + 63) / 64, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld,
-                         ncols, pr, w.R);
+    if (B1 > 0) {
+      step(ctx->stream, 0, B0, 0, 1);                          // group 0's first gram, then fork
+      WM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+      WM_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+      step(ctx->stream, 0, B0, 0, 2);
+      step(ctx->aux_stream, B0, B1, 0, 3);
+      for (int s = 1; s < p.nsteps; ++s) {
+        step(ctx->stream, 0, B0, s, 3);
+        step(ctx->aux_stream, B0, B1, s, 3);
+      }
+      WM_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+      WM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    } else {
+      for (int s = 0; s < p.nsteps; ++s) step(ctx->stream, 0, B0, s, 3);
     }
     WM_HIP(hipGetLastError());
     WM_HIP(hipMemcpyAsync(bits.data(), w.maxcos, (size_t)p.B * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     ++sweep;
     done = true;
-    for (int z = 0; z < p.B; ++z) { float mc; memcpy(&mc, &bits[z], 4); if (!(mc < CONV_COS)) done = false; }
+    for (int z = 0; z < p.B; ++z) { float mc; memcpy(&mc, &bits[z], 4); if (!(mc < conv_cos)) done = false; }
   }
   *sweeps_out = done ? sweep : -sweep;
   ctx->ref_last_sweeps = sweep;
@@ -549,6 +610,41 @@ int fetch_norms(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std:
   WM_HIP(hipMemcpyAsync(q2.data(), w.q2, q2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
   if (!with_q) std::fill(q2.begin(), q2.end(), 1.0);
+  return WM_OK;
+}
+
+// Q-free finalisation after jacobi_rows(with_q = false).  The rotated rows are b_i = s_i v_i^T
+// up to the scale drift of ~3e4 float32 rotations per row (v_rsq_f32 rounds cos^2 + sin^2 a few
+// 1e-8 below 1, every time); the DIRECTION v_i is good to the convergence threshold.  So the
+// singular value is measured on the untouched input instead:  T = A0 B^T  (T[:, i] = A0 b_i^T =
+// |b_i| s_i u_i), s_i = |T[:, i]| / |b_i| - the drift cancels, and T doubles as the left factor
+// of the embed (u_i = T[:, i] / (|b_i| s_i)).  b2 = |b_i|^2, and q2 is returned as
+// b2^2 / |T[:, i]|^2 so that sqrt(b2 / q2) is s_i like in the [A | I] formulation.
+//   A0: dense [B][L][M] copy of the input rows;  T: dense [B][L][Lp] (left on the device).
+int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0, float* T, std::vector<double>& b2,
+                  std::vector<double>& q2) {
+  hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, 0, w.b2, w.q2);
+  for (int z = 0; z < p.B; ++z)
+    WM_TRY(sgemm(ctx, false, true, p.L, p.Lp, p.M, 1.0f, A0 + (size_t)z * p.L * p.M, p.M, w.aug + (size_t)z * p.aug_ps, p.ld,
+                 0.0f, T + (size_t)z * p.L * p.Lp, p.Lp));
+  hipLaunchKernelGGL(k_rf_colnorms, dim3((p.Lp + 63) / 64, p.B), dim3(256), 0, ctx->stream, T, (size_t)p.L * p.Lp, p.L, p.Lp, w.q2);
+  WM_HIP(hipGetLastError());
+  b2.resize((size_t)p.B * p.Lp); q2.resize((size_t)p.B * p.Lp);
+  WM_HIP(hipMemcpyAsync(b2.data(), w.b2, b2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipMemcpyAsync(q2.data(), w.q2, q2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < b2.size(); ++i) {
+    if (q2[i] > 0.0 && b2[i] > 0.0) q2[i] = b2[i] * b2[i] / q2[i];
+    else { b2[i] = 0.0; q2[i] = 1.0; }
+  }
+  return WM_OK;
+}
+
+// copy the A part (first L rows, M columns) of every plane's Aug into a dense [B][L][M] array
+int copy_a_part(wm_ctx* ctx, const RefPlan& p, const RefWs& w, float* dst) {
+  for (int z = 0; z < p.B; ++z)
+    WM_HIP(hipMemcpy2DAsync(dst + (size_t)z * p.L * p.M, (size_t)p.M * 4, w.aug + (size_t)z * p.aug_ps, (size_t)p.ld * 4,
+                            (size_t)p.M * 4, p.L, hipMemcpyDeviceToDevice, ctx->stream));
   return WM_OK;
 }
 
@@ -592,17 +688,21 @@ int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int
   const RefPlan p = make_plan(H, W, n_planes);
   RefWs w;
   const size_t n_in = span_of(n_planes, H, W, row_stride, plane_stride);
-  WM_TRY(plan_workspace(ctx, p, w, (n_in + 3) / 4 + 4, 0));
+  // tmp1: uint8 input span; tmp2: A0 [B][L][M] | T [B][L][Lp]
+  WM_TRY(plan_workspace(ctx, p, w, (n_in + 3) / 4 + 4, (size_t)n_planes * p.L * (p.M + p.Lp)));
   WM_TRY(upload_pairs(ctx, p, w));
   uint8_t* d_in = (uint8_t*)w.tmp1;
+  float* d_a0 = w.tmp2;
+  float* d_t = w.tmp2 + (size_t)n_planes * p.L * p.M;
   WM_HIP(hipMemcpyAsync(d_in, planes, n_in, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
                      plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
+  WM_TRY(copy_a_part(ctx, p, w, d_a0));
   int sweeps = 0;
   WM_TRY(jacobi_rows(ctx, p, w, false, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2;
-  WM_TRY(fetch_norms(ctx, p, w, false, b2, q2));
+  WM_TRY(fetch_norms_t(ctx, p, w, d_a0, d_t, b2, q2));
   std::vector<int> order; std::vector<float> sig;
   for (int z = 0; z < n_planes; ++z) {
     sort_sigma(p, &b2[(size_t)z * p.Lp], &q2[(size_t)z * p.Lp], order, sig);
@@ -626,8 +726,9 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
   const size_t n_in = span_of(n_planes, H, W, row_stride, plane_stride);
   const size_t n_in16 = (n_in + 15) & ~(size_t)15;
   const size_t yw_elems = yw ? (size_t)n_planes * H * W : 0;
-  // tmp1: uint8 input + output spans (+ dense float Yw for the caller); tmp2: Yw in A layout [B][L][M]
-  WM_TRY(plan_workspace(ctx, p, w, (2 * n_in16) / 4 + 8 + yw_elems, (size_t)n_planes * p.L * p.M));
+  // tmp1: uint8 input + output spans (+ dense float Yw for the caller);
+  // tmp2: Yw in A layout [B][L][M] (starts as A0, the pixels) | T [B][L][Lp]
+  WM_TRY(plan_workspace(ctx, p, w, (2 * n_in16) / 4 + 8 + yw_elems, (size_t)n_planes * p.L * (p.M + p.Lp)));
   WM_TRY(upload_pairs(ctx, p, w));
   uint8_t* d_in = (uint8_t*)w.tmp1;
   uint8_t* d_out = d_in + n_in16;
@@ -640,15 +741,17 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
   hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
                      plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
   // Yw starts as A itself (exactly the pixels): copy the first L rows of every B part before rotating
-  for (int z = 0; z < n_planes; ++z)
-    WM_HIP(hipMemcpy2DAsync(d_yw + (size_t)z * yw_ps, (size_t)p.M * 4, w.aug + (size_t)z * p.aug_ps, (size_t)p.ld * 4,
-                            (size_t)p.M * 4, p.L, hipMemcpyDeviceToDevice, ctx->stream));
+  WM_TRY(copy_a_part(ctx, p, w, d_yw));
+  float* d_t = w.tmp2 + (size_t)n_planes * yw_ps;
   int sweeps = 0;
-  WM_TRY(jacobi_rows(ctx, p, w, true, &sweeps));
+  WM_TRY(jacobi_rows(ctx, p, w, false, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2;
-  WM_TRY(fetch_norms(ctx, p, w, true, b2, q2));
-  // d_i = alpha * sw[rank(i)] / (|b_i| |q_i|), rank < K        (S_[:K] = Sc[:K] + alpha*Sw[:K])
+  WM_TRY(fetch_norms_t(ctx, p, w, d_yw, d_t, b2, q2));
+  // U diag(alpha Sw) V^T = T diag(e) B  with  e_i = alpha * sw[rank(i)] / (s_i |b_i|^2), rank < K
+  // (u_i = T[:, i] / (|b_i| s_i), v_i^T = b_i / |b_i|;  S_[:K] = Sc[:K] + alpha*Sw[:K]).
+  // Directions below NULL_RATIO * s_1 carry rounding noise instead of singular vectors: nothing is
+  // injected there (DESIGN.md 9, rank-deficient planes).
   std::vector<float> d((size_t)n_planes * p.Lp, 0.0f);
   std::vector<int> order; std::vector<float> sig;
   for (int z = 0; z < n_planes; ++z) {
@@ -656,17 +759,18 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
     sort_sigma(p, pb, pq, order, sig);
     memcpy(sigma_c + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
     const float* sw = sigma_w + (size_t)z * sigma_w_plane_stride;
+    const double s1 = sig.empty() ? 0.0 : (double)sig[0];
     for (int k = 0; k < std::min(K, p.L); ++k) {
       const int i = order[k];
-      const double den = sqrt(pb[i] * pq[i]);
-      d[(size_t)z * p.Lp + i] = den > 0.0 ? (float)((double)alpha * (double)sw[k] / den) : 0.0f;
+      const double si = (double)sig[k];
+      d[(size_t)z * p.Lp + i] = (si > NULL_RATIO * s1 && pb[i] > 0.0) ? (float)((double)alpha * (double)sw[k] / (si * pb[i])) : 0.0f;
     }
   }
   WM_HIP(hipMemcpyAsync(w.dvec, d.data(), d.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, w.dvec);
-  // Yw += Qt^T (diag(d) B):   [L x Lp]^T-view of Qt (rows i, cols r < L) times [Lp x M]
+  // Yw += T (diag(e) B):   [L x Lp] times [Lp x M]
   for (int z = 0; z < n_planes; ++z)
-    WM_TRY(sgemm(ctx, true, false, p.L, p.M, p.Lp, 1.0f, w.aug + (size_t)z * p.aug_ps + p.M, p.ld,
+    WM_TRY(sgemm(ctx, false, false, p.L, p.M, p.Lp, 1.0f, d_t + (size_t)z * p.L * p.Lp, p.Lp,
                  w.aug + (size_t)z * p.aug_ps, p.ld, 1.0f, d_yw + (size_t)z * yw_ps, p.M));
   hipLaunchKernelGGL(k_rf_quant, dim3(8, H, p.B), dim3(256), 0, ctx->stream, d_yw, yw_ps, p.M, p.transpose ? 1 : 0,
                      d_out, (size_t)row_stride, plane_stride, d_ywout, H, W);
