@@ -907,22 +907,32 @@ int wm_ref_last_sweeps(wm_ctx* ctx, int* sweeps_out) {
 }
 
 // detect: _nc(Sw[:L], (S_cw - Sc) / max(alpha, 1e-8))     single:297-301, 284-289
+// detect over n_planes stego planes of one watermark (frames of a clip): batched SVDs, NC per plane
+int wm_ref_detect_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
+                            double* scores, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                            float alpha) {
+  WM_TRY(check_ref_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!sigma_c || !sigma_w || !scores) return set_err(WM_ERR_BADARG, "NULL argument");
+  const int L = std::min(H, W);
+  std::vector<float> s_cw((size_t)n_planes * L);
+  WM_TRY(wm_ref_sigma_planes_u8(ctx, stego, s_cw.data(), n_planes, H, W, row_stride, plane_stride));
+  const float a = fmaxf(alpha, 1e-8f);
+  std::vector<double> x(L), y(L);
+  for (int z = 0; z < n_planes; ++z) {
+    const float* scw = &s_cw[(size_t)z * L]; const float* sc = sigma_c + (size_t)z * L;
+    double sa = 0, sb = 0;
+    for (int i = 0; i < L; ++i) { x[i] = sigma_w[i]; y[i] = (double)((scw[i] - sc[i]) / a); sa += x[i]; sb += y[i]; }
+    sa /= L; sb /= L;
+    double cov = 0, va = 0, vb = 0;
+    for (int i = 0; i < L; ++i) { const double dx = x[i] - sa, dy = y[i] - sb; cov += dx * dy; va += dx * dx; vb += dy * dy; }
+    scores[z] = cov / (sqrt(va) * sqrt(vb) + 1e-8);
+  }
+  return WM_OK;
+}
+
 int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
                      double* score, int H, int W, int row_stride, float alpha) {
-  WM_TRY(check_ref_args(ctx, stego, 1, H, W, row_stride, (size_t)H * row_stride));
-  if (!sigma_c || !sigma_w || !score) return set_err(WM_ERR_BADARG, "NULL argument");
-  const int L = std::min(H, W);
-  std::vector<float> s_cw(L);
-  WM_TRY(wm_ref_sigma_u8(ctx, stego, s_cw.data(), H, W, row_stride));
-  const float a = fmaxf(alpha, 1e-8f);
-  double sa = 0, sb = 0;
-  std::vector<double> x(L), y(L);
-  for (int i = 0; i < L; ++i) { x[i] = sigma_w[i]; y[i] = (double)((s_cw[i] - sigma_c[i]) / a); sa += x[i]; sb += y[i]; }
-  sa /= L; sb /= L;
-  double cov = 0, va = 0, vb = 0;
-  for (int i = 0; i < L; ++i) { const double dx = x[i] - sa, dy = y[i] - sb; cov += dx * dy; va += dx * dx; vb += dy * dy; }
-  *score = cov / (sqrt(va) * sqrt(vb) + 1e-8);
-  return WM_OK;
+  return wm_ref_detect_planes_u8(ctx, stego, sigma_c, sigma_w, score, 1, H, W, row_stride, (size_t)H * row_stride, alpha);
 }
 
 }  // extern "C"

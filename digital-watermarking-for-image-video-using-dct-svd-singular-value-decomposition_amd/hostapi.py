@@ -77,6 +77,7 @@ SIGNATURES = {
     "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_extract_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f, _i],
     "wm_ref_detect_u8": [_vp, _vp, _vp, _vp, C.POINTER(C.c_double), _i, _i, _i, _f],
+    "wm_ref_detect_planes_u8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f],
     "wm_bgr_to_ycrcb_u8_dev": [_vp, _vp, _vp, _sz],
     "wm_ycrcb_to_bgr_u8_dev": [_vp, _vp, _vp, _sz],
     "wm_bgr_to_gray_u8_dev": [_vp, _vp, _vp, _sz],
@@ -454,6 +455,21 @@ class Context:
         self._call("wm_ref_detect_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
                    C.byref(score), H, W, W, float(alpha))
         return score.value
+
+    def ref_detect_planes(self, stegos: np.ndarray, sigma_c, sigma_w, alpha: float) -> np.ndarray:
+        """stegos uint8 [n, H, W] carrying one watermark; sigma_c [n, L], sigma_w [L] -> scores float64 [n]."""
+        if stegos.dtype != np.uint8 or stegos.ndim != 3:
+            raise ValueError("stego planes must be uint8 [n, H, W]")
+        stegos = np.ascontiguousarray(stegos)
+        n, H, W = stegos.shape
+        L = min(H, W)
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32); sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
+        if sc.shape != (n, L) or sw.shape != (L,):
+            raise ValueError("meta arrays do not match the plane size")
+        scores = np.empty(n, np.float64)
+        self._call("wm_ref_detect_planes_u8", _vp(stegos.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
+                   _vp(scores.ctypes.data), n, H, W, W, H * W, float(alpha))
+        return scores
 
     # ---- pixel-side kernels (colour, PSNR, SSIM, normalise) ----------------------
     _COLOR_OPS = {"bgr2ycrcb": 0, "ycrcb2bgr": 1, "bgr2gray": 2, "bgr2y": 3, "replace_y": 4}

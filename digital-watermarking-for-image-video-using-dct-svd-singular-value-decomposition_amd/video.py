@@ -96,52 +96,68 @@ def write_y4m(path: str, frames_y: np.ndarray, chroma: Optional[np.ndarray] = No
 # ---------------------------------------------------------------------------
 # array level: batches of luma frames
 # ---------------------------------------------------------------------------
-def prepare_watermark(ctx: hostapi.Context, wm_bgr: np.ndarray, H: int, W: int, key: bytes):
-    """resize -> gray -> keyed pixel shuffle -> tile SVD, once per video."""
+def prepare_watermark(ctx: hostapi.Context, wm_bgr: np.ndarray, H: int, W: int, key: bytes,
+                      tile: Optional[int] = TILE):
+    """resize -> gray -> keyed pixel shuffle -> SVD of its DCT, once per video.
+    tile=8: per-tile factors; tile=None: the reference's full-plane factors."""
     wm = hg.resize_area(wm_bgr, W, H)
     idx = hg.permutation_index(H, W, key)
     wy_s = hg.permute(hg.bgr_to_gray(wm).astype(np.float32), idx)
-    Uw, Sw, Vwt = ctx.svd_tiles(wy_s)
+    Uw, Sw, Vwt = ctx.svd_tiles(wy_s) if tile else ctx.ref_svd(wy_s, apply_dct=True)
     return Uw, Sw, Vwt, idx
 
 
+def _k_of(tile: Optional[int], kfrac: float, k_floor: int, H: int, W: int) -> int:
+    """K = max(8, int(kfrac * L)) (single:137) with L = 8 per tile or min(H, W) per plane."""
+    L = tile if tile else min(H, W)
+    return min(L, max(int(k_floor), int(kfrac * L)))
+
+
 def embed_frames(ctx: hostapi.Context, frames_y: np.ndarray, Sw: np.ndarray, alpha: float, K: int = 8,
-                 batch: int = 32):
-    """frames_y uint8 [N, H, W] -> (stego [N, H, W], Sc [N, nby, nbx, 8]); one K1 launch per batch."""
-    n = frames_y.shape[0]
+                 batch: int = 32, tile: Optional[int] = TILE):
+    """frames_y uint8 [N, H, W] -> (stego [N, H, W], Sc); one set of launches per batch.
+    tile=8: Sc [N, nby, nbx, 8] (K1); tile=None: Sc [N, min(H, W)] (batched full-plane SVDs)."""
+    n, H, W = frames_y.shape
     stego = np.empty_like(frames_y)
-    sc = np.empty((n, frames_y.shape[1] // TILE, frames_y.shape[2] // TILE, 8), np.float32)
+    sc = np.empty((n, H // TILE, W // TILE, 8) if tile else (n, min(H, W)), np.float32)
     for b0 in range(0, n, batch):
-        s, c, _ = ctx.embed_tiles(frames_y[b0:b0 + batch], Sw, alpha, K)
+        if tile:
+            s, c, _ = ctx.embed_tiles(frames_y[b0:b0 + batch], Sw, alpha, K)
+        else:
+            s, c, _ = ctx.ref_embed_planes(frames_y[b0:b0 + batch], Sw, alpha, K)
         stego[b0:b0 + batch] = s; sc[b0:b0 + batch] = c
     return stego, sc
 
 
 def extract_frames_mean(ctx: hostapi.Context, frames_y: np.ndarray, Sc: np.ndarray, Uw, Vwt, alpha: float,
-                        K: int = 8, batch: int = 32) -> np.ndarray:
+                        K: int = 8, batch: int = 32, tile: Optional[int] = TILE) -> np.ndarray:
     """Mean over frames of the scrambled-watermark estimates (float32 [H, W])."""
     n, H, W = frames_y.shape
     acc = np.zeros((H, W), np.float64)
     for b0 in range(0, n, batch):
-        w = ctx.extract_tiles(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Uw, Vwt, alpha, K)
+        if tile:
+            w = ctx.extract_tiles(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Uw, Vwt, alpha, K)
+        else:
+            w = ctx.ref_extract_planes(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Uw, Vwt, alpha, K)
         acc += w.sum(axis=0, dtype=np.float64)
     return (acc / max(n, 1)).astype(np.float32)
 
 
 def detect_frames(ctx: hostapi.Context, frames_y: np.ndarray, Sc: np.ndarray, Sw: np.ndarray, alpha: float,
-                  batch: int = 32) -> np.ndarray:
+                  batch: int = 32, tile: Optional[int] = TILE) -> np.ndarray:
     scores = np.empty(frames_y.shape[0], np.float64)
     for b0 in range(0, frames_y.shape[0], batch):
-        scores[b0:b0 + batch] = ctx.detect_tiles(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Sw, alpha)
+        f = ctx.detect_tiles if tile else ctx.ref_detect_planes
+        scores[b0:b0 + batch] = f(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Sw, alpha)
     return scores
 
 
 def embed_frames_sharded(ctx: hostapi.Context, frames_y: np.ndarray, Sw: np.ndarray, alpha: float, K: int = 8,
-                         rank: int = 0, world_size: int = 1, batch: int = 32):
+                         rank: int = 0, world_size: int = 1, batch: int = 32, tile: Optional[int] = TILE):
     """This rank's share [r*N//W, (r+1)*N//W) of a batch of frames (no collective:
     the watermark sigma was broadcast beforehand, sharding.broadcast_watermark)."""
     lo, hi = sharding.frame_range(rank, world_size, frames_y.shape[0])
-    stego, sc = embed_frames(ctx, frames_y[lo:hi], Sw, alpha, K, batch)
+    stego, sc = embed_frames(ctx, frames_y[lo:hi], Sw, alpha, K, batch, tile)
     return (lo, hi), stego, sc
 
 
@@ -155,9 +171,13 @@ def _marked(n_frames: int, frame_interval: int) -> np.ndarray:
 def embed_watermark_video(host_video_path: str, watermark_path: str, output_video_path: str,
                           metadata_path: str, alpha: float = 0.1, frame_interval: int = 1, *,
                           password: str = "", nonce: Optional[bytes] = None, kfrac: float = hg.K_FRAC_DEFAULT,
-                          k_floor: int = 8, batch: int = 32, device: int = 0):
+                          k_floor: int = 8, batch: int = 32, device: int = 0, tile: Optional[int] = TILE):
     """Embed the watermark into the luma of every ``frame_interval``-th frame of a
-    .y4m video.  Returns (output_video_path, metadata_path, mean PSNR of marked frames)."""
+    .y4m video.  Returns (output_video_path, metadata_path, mean PSNR of marked frames).
+    tile=8: 8x8-block formulation (fast path); tile=None: one SVD per frame like the reference's
+    image embed (batched over the frames of a chunk; use a smaller ``batch``, e.g. 8)."""
+    if tile not in (TILE, None):
+        raise ValueError("tile must be 8 or None")
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để nhúng.")
     ctx = hostapi.Context(device)
@@ -167,8 +187,8 @@ def embed_watermark_video(host_video_path: str, watermark_path: str, output_vide
         if nonce is None:
             nonce = os.urandom(8)
         key = hg.derive_key(password, nonce)
-        Uw, Sw, Vwt, _ = prepare_watermark(ctx, hg.read_image_bgr(watermark_path), H, W, key)
-        K = min(TILE, max(int(k_floor), int(kfrac * TILE)))
+        Uw, Sw, Vwt, _ = prepare_watermark(ctx, hg.read_image_bgr(watermark_path), H, W, key, tile)
+        K = _k_of(tile, kfrac, k_floor, H, W)
         sc_all, psnrs, n_frames = [], [], 0
         with open(output_video_path, "wb") as out:
             out.write(vid.header_line)
@@ -177,7 +197,7 @@ def embed_watermark_video(host_video_path: str, watermark_path: str, output_vide
             def flush():
                 ys = [p[1] for p in pend if p[3]]
                 if ys:
-                    st, sc = embed_frames(ctx, np.stack(ys), Sw, alpha, K, batch)
+                    st, sc = embed_frames(ctx, np.stack(ys), Sw, alpha, K, batch, tile)
                     sc_all.append(sc)
                 j = 0
                 for line, y, chroma, marked in pend:
@@ -193,12 +213,12 @@ def embed_watermark_video(host_video_path: str, watermark_path: str, output_vide
                 if len(pend) >= batch * max(1, frame_interval):
                     flush()
             flush()
-        Sc = np.concatenate(sc_all) if sc_all else np.zeros((0, H // TILE, W // TILE, 8), np.float32)
+        Sc = np.concatenate(sc_all) if sc_all else np.zeros((0, H // TILE, W // TILE, 8) if tile else (0, min(H, W)), np.float32)
         digest = hg.hmac_digest(key, [Sc, Uw, Vwt])
         np.savez_compressed(metadata_path, mode="video_gray", payload_type="image", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw,
                             shape=np.array((H, W)), alpha=float(alpha), kfrac=float(kfrac),
                             frame_interval=np.int32(frame_interval), n_frames=np.int32(n_frames),
-                            tile=np.int32(TILE), k_floor=np.int32(k_floor),
+                            tile=np.int32(tile or 0), k_floor=np.int32(k_floor),
                             nonce=np.frombuffer(nonce, dtype=np.uint8), digest=np.frombuffer(digest, dtype=np.uint8))
         return output_video_path, metadata_path, float(np.mean(psnrs)) if psnrs else 99.0
     finally:
@@ -210,6 +230,10 @@ def _load_video_meta(metadata_path: str):
     if str(data["mode"]) != "video_gray":
         raise ValueError("metadata was not written by embed_watermark_video")
     return data
+
+
+def _meta_tile(data) -> Optional[int]:
+    return int(data["tile"]) or None
 
 
 def _marked_luma(stego_video_path: str, data) -> np.ndarray:
@@ -240,8 +264,9 @@ def extract_watermark_video(stego_video_path: str, metadata_path: str, output_im
     ctx = hostapi.Context(device)
     try:
         ys = _marked_luma(stego_video_path, data)
-        K = min(TILE, max(int(data["k_floor"]), int(float(data["kfrac"]) * TILE)))
-        wy_s = extract_frames_mean(ctx, ys, data["Sc"], data["Uw"], data["Vwt"], float(data["alpha"]), K, batch)
+        tile = _meta_tile(data)
+        K = _k_of(tile, float(data["kfrac"]), int(data["k_floor"]), H, W)
+        wy_s = extract_frames_mean(ctx, ys, data["Sc"], data["Uw"], data["Vwt"], float(data["alpha"]), K, batch, tile)
         wy = hg.unpermute(wy_s, hg.permutation_index(H, W, key))
         img = ctx.normalize_u8(wy, normalize)
     finally:
@@ -260,7 +285,7 @@ def detect_watermark_video(stego_video_path: str, metadata_path: str, thresh: fl
     ctx = hostapi.Context(device)
     try:
         ys = _marked_luma(stego_video_path, data)
-        scores = detect_frames(ctx, ys, data["Sc"], data["Sw"], float(data["alpha"]), batch)
+        scores = detect_frames(ctx, ys, data["Sc"], data["Sw"], float(data["alpha"]), batch, _meta_tile(data))
     finally:
         ctx.close()
     mean = float(scores.mean()) if scores.size else 0.0

@@ -208,6 +208,12 @@ int wm_ref_last_sweeps(wm_ctx* ctx, int* sweeps_out);
 int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
                      double* score, int H, int W, int row_stride, float alpha);
 
+/* The same for n_planes stego planes carrying ONE watermark (frames of a clip): their SVDs
+ * run as one batch.  sigma_c [n_planes][L], sigma_w [L], scores [n_planes]. */
+int wm_ref_detect_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
+                            double* scores, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                            float alpha);
+
 /* ==========================================================================
  * Pixel-side kernels either side of the hot path.  Colour
  * conversion is OpenCV's 8-bit fixed point, bit-exact integer work; images

@@ -83,3 +83,50 @@ def test_video_embed_extract_detect(tmp_path, gpu_ctx):
     assert parts[0][0] == (0, 4) and parts[1][0] == (4, 9)
     assert np.array_equal(np.concatenate([parts[0][1], parts[1][1]]), st_all)
     assert np.array_equal(np.concatenate([parts[0][2], parts[1][2]]), sc_all)
+
+
+@pytest.mark.gpu
+def test_video_fullframe_mode(tmp_path, gpu_ctx):
+    """tile=None: every marked frame gets the reference's full-plane embed (one SVD per frame,
+    batched); the meta carries per-frame Sc [n, L] and the full-plane Uw/Vwt."""
+    v, p, ys, chroma = _video(tmp_path)
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    wm = np.random.default_rng(5).integers(0, 256, (16, 24, 3), dtype=np.uint8)
+    wp = str(tmp_path / "wm.png"); assert hg.write_png(wp, wm)
+    outp, meta, ps = v.embed_watermark_video(p, wp, str(tmp_path / "out_ff.y4m"), str(tmp_path / "vm_ff.npz"),
+                                             alpha=0.15, frame_interval=2, password="pw", nonce=bytes(8), batch=3,
+                                             tile=None)
+    data = np.load(meta, allow_pickle=False)
+    assert int(data["tile"]) == 0 and data["Sc"].shape == (5, 64) and data["Uw"].shape == (64, 64)
+    assert data["Vwt"].shape == (64, 96)
+    vid = v.Y4M(outp); got = [(y.copy(), c.copy()) for _, y, c in vid]; vid.close()
+    key = o.derive_key("pw", bytes(8)); idx = o.permutation(64, 96, o.rng_from_key(key))
+    wy_s = o.permute(o.bgr_to_gray(o.resize_area(wm, 96, 64)).astype(np.float32), idx)
+    for i, (y, c) in enumerate(got):
+        assert np.array_equal(c, chroma[i])
+        if i % 2:
+            assert np.array_equal(y, ys[i])
+        else:
+            ref = o.embed_plane(ys[i].astype(np.float32), wy_s, 0.15, 0.6, None)
+            assert np.abs(y.astype(int) - ref["stego"].astype(int)).max() <= 1
+            assert np.mean(y != ref["stego"]) < 5e-3
+            assert np.max(np.abs(data["Sc"][i // 2] - ref["Sc"])) / ref["Sc"][0] < 1e-5
+    ok, mean, scores = v.detect_watermark_video(outp, meta)
+    assert ok and mean > 0.9 and scores.shape == (5,)
+    ok0, _, _ = v.detect_watermark_video(p, meta)
+    assert not ok0
+    wout = v.extract_watermark_video(outp, meta, str(tmp_path / "w_ff.png"), password="pw")
+    ex = hg.read_image_bgr(wout)[..., 0]
+    # oracle: per-frame full-plane extract with the stored factors (incl. the reference's [:L,:L]
+    # truncation on this non-square plane), mean over frames, unscramble, min-max normalise
+    est = np.mean([o.extract_plane(got[2 * j][0].astype(np.float32), data["Sc"][j], data["Uw"], data["Vwt"],
+                                   0.15, 0.6, 64, 96, None) for j in range(5)], axis=0)
+    want = np.clip(o.normalize_minmax(o.unpermute(est.astype(np.float32), idx)), 0, 255).astype(np.uint8)
+    assert np.abs(ex.astype(int) - want.astype(int)).max() <= 2
+    assert np.corrcoef(ex.ravel().astype(float), want.ravel().astype(float))[0, 1] > 0.999
+    with pytest.raises(ValueError):
+        v.embed_watermark_video(p, wp, outp, meta, password="pw", tile=4)
+    # batched detect == per-frame detect
+    marked = np.stack([g[0] for g in got[::2]])
+    one = [gpu_ctx.ref_detect(marked[i], data["Sc"][i], data["Sw"], 0.15) for i in range(5)]
+    assert np.allclose(gpu_ctx.ref_detect_planes(marked, data["Sc"], data["Sw"], 0.15), one, atol=1e-6)
