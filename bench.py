@@ -52,7 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(frames_u8, wys, alpha, stego_gpu, sc_gpu):
+def cpu_baseline(frames_u8, wys, alpha, stego_gpu, sc_gpu, wm_gpu):
     """Oracle (NumPy restatement, tile-mode) embed+extract on a bounded sample
     of the same workload, timed on this box's host cores."""
     from oracle import wm_oracle as o
@@ -62,12 +62,13 @@ def cpu_baseline(frames_u8, wys, alpha, stego_gpu, sc_gpu):
     t0 = time.perf_counter(); c0 = time.process_time()
     wm_svd = o.watermark_decompose(wys, 8)           # once per watermark, like the GPU path
     t_wm = time.perf_counter() - t0
-    worst_lsb, worst_sig = 0, 0.0
+    worst_lsb, worst_sig, worst_wm = 0, 0.0, 0.0
     psnr_cpu, psnr_gpu = [], []
     t1 = time.perf_counter()
     for i in range(n):
         e = o.embed_plane(frames_u8[i].astype(np.float32), wys, alpha, 0.6, tile=8, wm_svd=wm_svd)
-        o.extract_plane(e["stego"].astype(np.float32), e["Sc"], e["Uw"], e["Vwt"], alpha, 0.6, H, W, 8)
+        wm_cpu = o.extract_plane(e["stego"].astype(np.float32), e["Sc"], e["Uw"], e["Vwt"], alpha, 0.6, H, W, 8)
+        worst_wm = max(worst_wm, float(np.abs(wm_cpu - wm_gpu[i]).max() / max(float(np.abs(wm_cpu).max()), 1e-30)))
         d = np.abs(e["stego"].astype(np.int16) - stego_gpu[i].astype(np.int16))
         worst_lsb = max(worst_lsb, int(d.max()))
         rel = np.max(np.abs(sc_gpu[i] - e["Sc"]) / np.maximum(e["Sc"][..., :1], 1e-30))
@@ -80,7 +81,7 @@ def cpu_baseline(frames_u8, wys, alpha, stego_gpu, sc_gpu):
                 sample=f"{n} frames {W}x{H} Y, NumPy oracle tile-mode embed+extract "
                        f"(watermark SVD {t_wm:.2f}s once, excluded like on the GPU)",
                 host_cpus=os.cpu_count()), \
-        dict(stego_max_lsb=worst_lsb, sigma_max_rel=worst_sig,
+        dict(stego_max_lsb=worst_lsb, sigma_max_rel=worst_sig, extract_max_rel_to_range=worst_wm,
              psnr_cpu=float(np.mean(psnr_cpu)), psnr_gpu=float(np.mean(psnr_gpu)))
 
 
@@ -190,6 +191,10 @@ def main():
         ctx.svd_tiles_f32_dev(wys.data_ptr(), Uw.data_ptr(), Sw.data_ptr(), Vwt.data_ptr(), 1, H, W, W, H * W)
         torch.cuda.synchronize(dev)
     shard.broadcast_watermark([Uw, Vwt], src=0)      # extract-side meta: once per watermark
+    # once per watermark as well: fold the IDCT into the factors (Ux = D^T Uw, Vxt = Vwt D), so the
+    # per-frame extract is sigma + a rank-8 product (wm_extract_tiles_px_u8_dev)
+    Ux = torch.empty_like(Uw); Vxt = torch.empty_like(Vwt)
+    ctx.tile_factors_to_pixel_dev(Uw.data_ptr(), Vwt.data_ptr(), Ux.data_ptr(), Vxt.data_ptr(), nt)
 
     # The path's exchange step: rank 0's watermark singular values reach every rank once per
     # step (RCCL broadcast).  It is double-buffered and issued asynchronously for step k+1
@@ -213,8 +218,8 @@ def main():
                                F, H, W, W, H * W, 0, alpha, K)
         if record is not None:
             ctx.event_record(record + 1)
-        ctx.extract_tiles_u8_dev(stego.data_ptr(), sigma_c.data_ptr(), Uw.data_ptr(), Vwt.data_ptr(),
-                                 wm_out.data_ptr(), F, H, W, W, H * W, 0, alpha, K)
+        ctx.extract_tiles_px_u8_dev(stego.data_ptr(), sigma_c.data_ptr(), Ux.data_ptr(), Vxt.data_ptr(),
+                                    wm_out.data_ptr(), F, H, W, W, H * W, 0, alpha, K)
 
     def barrier():
         if world > 1:
@@ -281,7 +286,8 @@ def main():
             n = min(a.cpu_frames, F)
             cb, par = cpu_baseline(frames[:n].cpu().numpy(), wys_np, alpha,
                                    stego[:n].cpu().numpy(),
-                                   sigma_c[:n].cpu().numpy().reshape(n, H // 8, W // 8, 8))
+                                   sigma_c[:n].cpu().numpy().reshape(n, H // 8, W // 8, 8),
+                                   wm_out[:n].cpu().numpy())
             out["cpu_baseline"] = cb
             out["parity"] = par
         print(json.dumps(out), flush=True)

@@ -697,4 +697,43 @@ WM_HD void extract_tile(const float (&s_cw)[8], const float (&sc)[8], const floa
   idct8x8(out);
 }
 
+// ---- the same with PIXEL-domain factors -------------------------------------
+// idct2(Uw diag(s) Vwt) = (D^T Uw) diag(s) (Vwt D): with Ux = D^T Uw and Vxt = Vwt D
+// prepared once per watermark (factors_to_pixel) the per-frame work is the rank-8 product
+// alone - no IDCT - and it packs over column pairs.
+WM_HD void factors_to_pixel(float (&u)[8][8], float (&vt)[8][8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c)     // Ux = D^T Uw: inverse transform along the row index
+    idct8(u[0][c], u[1][c], u[2][c], u[3][c], u[4][c], u[5][c], u[6][c], u[7][c]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)     // Vxt = Vwt D: inverse transform along the column index
+    idct8(vt[i][0], vt[i][1], vt[i][2], vt[i][3], vt[i][4], vt[i][5], vt[i][6], vt[i][7]);
+}
+
+WM_HD void extract_tile_px(const float (&s_cw)[8], const float (&sc)[8], const float inv_alpha,
+                           const float (&keep)[8], const float (&ux)[8][8],
+                           const float (&vxt)[8][8], float (&out)[8][8]) {
+  float sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sh[i] = (s_cw[i] - sc[i]) * inv_alpha * keep[i];
+  v2f vs[8][4];                    // diag(sh) Vxt, packed over column pairs
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+      const v2f v = {vxt[i][2 * cp], vxt[i][2 * cp + 1]};
+      vs[i][cp] = v * splat2(sh[i]);
+    }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+      v2f acc = splat2(ux[r][0]) * vs[0][cp];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) acc = fma2(splat2(ux[r][i]), vs[i][cp], acc);
+      out[r][2 * cp] = acc[0];
+      out[r][2 * cp + 1] = acc[1];
+    }
+}
+
 }  // namespace wm

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_svd_tiles(const float* __restrict__
 // ---------------------------------------------------------------------------
 // K2+K4  fused extract
 // ---------------------------------------------------------------------------
-template <bool ALIGNED, bool VECF>
+template <bool ALIGNED, bool VECF, bool PX>
 __global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
     const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
     const float* __restrict__ Uw, const float* __restrict__ Vwt, float* __restrict__ out,
@@ -376,10 +376,24 @@ __global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
   const size_t mi = (plane * uv_plane_stride + (size_t)t) * 64;
   load_mat_f32(Uw + mi, uw);
   load_mat_f32(Vwt + mi, vwt);
-  wm::extract_tile(s, sc, inv_alpha, keep, uw, vwt, a);
+  if (PX) wm::extract_tile_px(s, sc, inv_alpha, keep, uw, vwt, a);
+  else wm::extract_tile(s, sc, inv_alpha, keep, uw, vwt, a);
   float* o = out + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
 #pragma unroll
   for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
+}
+
+// per-watermark preparation for the PX extract: Ux = D^T Uw, Vxt = Vwt D (in place allowed)
+__global__ __launch_bounds__(WAVE) void k_factors_to_pixel(const float* Uw, const float* Vwt, float* Ux, float* Vxt,
+                                                          const size_t n_tiles) {
+  const size_t t = (size_t)blockIdx.x * WAVE + threadIdx.x;
+  if (t >= n_tiles) return;
+  float u[8][8], vt[8][8];
+  load_mat_f32(Uw + t * 64, u);
+  load_mat_f32(Vwt + t * 64, vt);
+  wm::factors_to_pixel(u, vt);
+  store_mat_f32(Ux + t * 64, u);
+  store_mat_f32(Vxt + t * 64, vt);
 }
 
 // ---------------------------------------------------------------------------
@@ -750,9 +764,9 @@ int wm_svd_tiles_f32_dev(wm_ctx* ctx, const float* planes, float* U, float* S, f
 }
 
 // ---- K2+K4 -----------------------------------------------------------------
-int wm_extract_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
-                            const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
-                            size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+static int extract_tiles_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                             const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                             size_t plane_stride, size_t uv_plane_stride, float alpha, int K, bool px) {
   WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
   if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
   if (K < 0 || K > 8) return set_err(WM_ERR_BADARG, "K must be in 0..8");
@@ -769,14 +783,48 @@ int wm_extract_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigm
   const bool al = u8_aligned(stego, stego, row_stride, plane_stride);
   const bool vf = f32_vec_ok(out, (size_t)W, g.HW);
   const dim3 grid = tile_grid(g, n_planes), block(WAVE);
-#define WM_LAUNCH_EXTRACT(A, V)                                                                   \
-  hipLaunchKernelGGL((k_extract_tiles<A, V>), grid, block, 0, ctx->stream, stego, sigma_c, Uw, Vwt, \
+#define WM_LAUNCH_EXTRACT(A, V, P)                                                                    \
+  hipLaunchKernelGGL((k_extract_tiles<A, V, P>), grid, block, 0, ctx->stream, stego, sigma_c, Uw, Vwt, \
                      out, g, uv_plane_stride, inv_alpha, K, ctx->d_status)
-  if (al && vf) WM_LAUNCH_EXTRACT(true, true);
-  else if (al) WM_LAUNCH_EXTRACT(true, false);
-  else if (vf) WM_LAUNCH_EXTRACT(false, true);
-  else WM_LAUNCH_EXTRACT(false, false);
+  if (px) {
+    if (al && vf) WM_LAUNCH_EXTRACT(true, true, true);
+    else if (al) WM_LAUNCH_EXTRACT(true, false, true);
+    else if (vf) WM_LAUNCH_EXTRACT(false, true, true);
+    else WM_LAUNCH_EXTRACT(false, false, true);
+  } else {
+    if (al && vf) WM_LAUNCH_EXTRACT(true, true, false);
+    else if (al) WM_LAUNCH_EXTRACT(true, false, false);
+    else if (vf) WM_LAUNCH_EXTRACT(false, true, false);
+    else WM_LAUNCH_EXTRACT(false, false, false);
+  }
 #undef WM_LAUNCH_EXTRACT
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+int wm_extract_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                            const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                            size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+  return extract_tiles_dev(ctx, stego, sigma_c, Uw, Vwt, out, n_planes, H, W, row_stride, plane_stride,
+                           uv_plane_stride, alpha, K, false);
+}
+
+int wm_extract_tiles_px_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Ux,
+                               const float* Vxt, float* out, int n_planes, int H, int W, int row_stride,
+                               size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+  return extract_tiles_dev(ctx, stego, sigma_c, Ux, Vxt, out, n_planes, H, W, row_stride, plane_stride,
+                           uv_plane_stride, alpha, K, true);
+}
+
+int wm_tile_factors_to_pixel_dev(wm_ctx* ctx, const float* Uw, const float* Vwt, float* Ux, float* Vxt,
+                                 size_t n_tiles) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  if (n_tiles == 0) return WM_OK;
+  if (!Uw || !Vwt || !Ux || !Vxt || (((uintptr_t)Uw | (uintptr_t)Vwt | (uintptr_t)Ux | (uintptr_t)Vxt) & 15u))
+    return set_err(WM_ERR_BADARG, "factor arrays are NULL or not 16-byte aligned");
+  if (n_tiles > ((size_t)1 << 31)) return set_err(WM_ERR_BADARG, "too many tiles");
+  hipLaunchKernelGGL(k_factors_to_pixel, dim3((unsigned)((n_tiles + WAVE - 1) / WAVE)), dim3(WAVE), 0, ctx->stream,
+                     Uw, Vwt, Ux, Vxt, n_tiles);
   WM_HIP(hipGetLastError());
   return WM_OK;
 }

@@ -63,6 +63,8 @@ SIGNATURES = {
     "wm_svd_tiles_f32_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz],
     "wm_svd_tiles_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz],
     "wm_extract_tiles_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_extract_tiles_px_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_tile_factors_to_pixel_dev": [_vp, _vp, _vp, _vp, _vp, _sz],
     "wm_extract_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_reconstruct_tiles_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "wm_reconstruct_tiles": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
@@ -247,6 +249,15 @@ class Context:
                              plane_stride, uv_plane_stride, alpha, K):
         self._call("wm_extract_tiles_u8_dev", _vp(stego), _vp(sigma_c), _vp(Uw), _vp(Vwt), _vp(out),
                    n_planes, H, W, row_stride, plane_stride, uv_plane_stride, alpha, K)
+
+    def extract_tiles_px_u8_dev(self, stego, sigma_c, Ux, Vxt, out, n_planes, H, W, row_stride,
+                                plane_stride, uv_plane_stride, alpha, K):
+        """extract_tiles_u8_dev with pixel-domain factors (tile_factors_to_pixel_dev)."""
+        self._call("wm_extract_tiles_px_u8_dev", _vp(stego), _vp(sigma_c), _vp(Ux), _vp(Vxt), _vp(out),
+                   n_planes, H, W, row_stride, plane_stride, uv_plane_stride, alpha, K)
+
+    def tile_factors_to_pixel_dev(self, Uw, Vwt, Ux, Vxt, n_tiles):
+        self._call("wm_tile_factors_to_pixel_dev", _vp(Uw), _vp(Vwt), _vp(Ux), _vp(Vxt), n_tiles)
 
     def reconstruct_tiles_dev(self, Uw, sw_hat, Vwt, out, n_planes, H, W):
         self._call("wm_reconstruct_tiles_dev", _vp(Uw), _vp(sw_hat), _vp(Vwt), _vp(out), n_planes, H, W)

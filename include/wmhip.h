@@ -125,6 +125,20 @@ int wm_extract_tiles_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigm
                             const float* Uw, const float* Vwt, float* out,
                             int n_planes, int H, int W, int row_stride, size_t plane_stride,
                             size_t uv_plane_stride, float alpha, int K);
+
+/* Per-watermark preparation for wm_extract_tiles_px_u8_dev: the orthonormal DCT moves into
+ * the factors, idct2(Uw diag(s) Vwt) = (D^T Uw) diag(s) (Vwt D) per 8x8 tile:
+ *   Ux = D^T Uw,  Vxt = Vwt D   (n_tiles matrices of 8x8 each; in place allowed).
+ * No reference counterpart: single:214-218 recomputes the product and the IDCT per call. */
+int wm_tile_factors_to_pixel_dev(wm_ctx* ctx, const float* Uw, const float* Vwt, float* Ux, float* Vxt,
+                                 size_t n_tiles);
+
+/* wm_extract_tiles_u8_dev with the factors already in the pixel domain (above): same
+ * result up to float32 rounding, without the per-tile IDCT (frames of a clip share one
+ * watermark, so the preparation is paid once). */
+int wm_extract_tiles_px_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Ux,
+                               const float* Vxt, float* out, int n_planes, int H, int W, int row_stride,
+                               size_t plane_stride, size_t uv_plane_stride, float alpha, int K);
 int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
                         const float* Uw, const float* Vwt, float* out,
                         int n_planes, int H, int W, int row_stride, size_t plane_stride,

@@ -255,3 +255,49 @@ def test_two_contexts_from_two_threads(hostapi):
     for a, b in zip(results[0], results[1]):
         assert np.array_equal(a, b)
     assert np.abs(results[0][0].astype(int) - ref["stego"].astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("K", [8, 5])
+def test_extract_with_pixel_domain_factors(gpu_ctx, K):
+    """wm_tile_factors_to_pixel_dev + wm_extract_tiles_px_u8_dev: the IDCT is folded into the
+    factors once per watermark; the per-frame result matches the DCT-domain entry point and the
+    oracle, for several frames sharing the factors and for a ragged plane."""
+    alpha = 0.15
+    for H, W in ((64, 96), (52, 83)):
+        Hb, Wb = H // 8 * 8, W // 8 * 8
+        host, wys = _inputs(H, W)
+        frames = np.stack([host, np.random.default_rng(3).integers(0, 256, (H, W), dtype=np.uint8)])
+        refs = [o.embed_plane(f.astype(np.float32), wys, alpha, kfrac=0.0, tile=8, k_floor=K) for f in frames]
+        st = np.stack([r["stego"] for r in refs])
+        sc = np.stack([r["Sc"] for r in refs]).reshape(2, -1, 8)
+        Uw, Vwt = refs[0]["Uw"].reshape(-1, 8, 8), refs[0]["Vwt"].reshape(-1, 8, 8)
+        nt = Uw.shape[0]
+        d = {k: gpu_ctx.malloc(v) for k, v in dict(st=st.nbytes, sc=sc.nbytes, U=Uw.nbytes, V=Vwt.nbytes, Ux=Uw.nbytes,
+                                                   Vx=Vwt.nbytes, o1=2 * H * W * 4, o2=2 * H * W * 4).items()}
+        gpu_ctx.h2d(d["st"], st); gpu_ctx.h2d(d["sc"], np.ascontiguousarray(sc))
+        gpu_ctx.h2d(d["U"], np.ascontiguousarray(Uw)); gpu_ctx.h2d(d["V"], np.ascontiguousarray(Vwt))
+        gpu_ctx.tile_factors_to_pixel_dev(d["U"], d["V"], d["Ux"], d["Vx"], nt)
+        gpu_ctx.extract_tiles_u8_dev(d["st"], d["sc"], d["U"], d["V"], d["o1"], 2, H, W, W, H * W, 0, alpha, K)
+        gpu_ctx.extract_tiles_px_u8_dev(d["st"], d["sc"], d["Ux"], d["Vx"], d["o2"], 2, H, W, W, H * W, 0, alpha, K)
+        o1 = np.empty((2, H, W), np.float32); o2 = np.empty((2, H, W), np.float32)
+        gpu_ctx.d2h(o1, d["o1"]); gpu_ctx.d2h(o2, d["o2"]); gpu_ctx.check_status()
+        # the factors themselves: Ux = D^T Uw, Vxt = Vwt D per tile
+        Ux = np.empty_like(Uw); Vx = np.empty_like(Vwt)
+        gpu_ctx.d2h(Ux, d["Ux"]); gpu_ctx.d2h(Vx, d["Vx"])
+        D = o.dct_basis(8).astype(np.float64)
+        assert np.abs(Ux - np.einsum("kr,tki->tri", D, Uw)).max() < 2e-6
+        assert np.abs(Vx - np.einsum("tik,kc->tic", Vwt, D)).max() < 2e-6
+        assert np.abs(o1 - o2).max() < 1e-3 * max(1.0, np.abs(o1).max())
+        for f in range(2):
+            wo = o.extract_plane(st[f].astype(np.float32), refs[f]["Sc"], refs[0]["Uw"], refs[0]["Vwt"], alpha, 0.0,
+                                 H, W, 8, k_floor=K)
+            assert np.abs(o2[f] - wo).max() < 2e-2
+            assert np.all(o2[f][Hb:, :] == 0) and np.all(o2[f][:, Wb:] == 0)
+        # in-place conversion gives the same factors
+        gpu_ctx.tile_factors_to_pixel_dev(d["U"], d["V"], d["U"], d["V"], nt)
+        U2 = np.empty_like(Uw); gpu_ctx.d2h(U2, d["U"])
+        assert np.array_equal(U2, Ux)
+        for v in d.values():
+            gpu_ctx.free(v)
+    with pytest.raises(ValueError):
+        gpu_ctx.tile_factors_to_pixel_dev(0, 0, 0, 0, 4)

@@ -77,6 +77,9 @@ def main():
     timed("sigma", lambda: ctx.sigma_tiles_u8_dev(d_stego, d_sc, F, H, W, W, H * W), 1.5 * P * F)
     ctx.embed_tiles_u8_dev(d_host, d_S, d_stego, d_sc, None, F, H, W, W, H * W, 0, a.alpha, 8)
     timed("extract", lambda: ctx.extract_tiles_u8_dev(d_stego, d_sc, d_U, d_V, d_out, F, H, W, W, H * W, 0, a.alpha, 8), 10.5 * P * F)
+    d_Ux = ctx.malloc(nt * 64 * 4); d_Vx = ctx.malloc(nt * 64 * 4)
+    timed("factors_px", lambda: ctx.tile_factors_to_pixel_dev(d_U, d_V, d_Ux, d_Vx, nt), 4.0 * nt * 256)
+    timed("extract_px", lambda: ctx.extract_tiles_px_u8_dev(d_stego, d_sc, d_Ux, d_Vx, d_out, F, H, W, W, H * W, 0, a.alpha, 8), 10.5 * P * F)
     timed("detect", lambda: ctx.detect_tiles_u8_dev(d_stego, d_sc, d_S, d_scores, F, H, W, W, H * W, 0, a.alpha), 2.0 * P * F)
     # pixel-side streaming kernels (device-resident): algorithmic bytes / HIP-event time
     n_px = F * H * W
