@@ -50,6 +50,15 @@ struct wm_ctx {
 };
 
 namespace wmi {
+// first statement of every entry point that takes a context: NULL check, and make the
+// context's device current (a process may hold contexts on several devices; hipMalloc and
+// kernel launches follow the calling thread's current device)
+inline int use_ctx(const wm_ctx* ctx) {
+  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return set_err(WM_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  return WM_OK;
+}
 // grow-only device buffer (synchronises the stream before freeing the old one)
 int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what);
 }  // namespace wmi

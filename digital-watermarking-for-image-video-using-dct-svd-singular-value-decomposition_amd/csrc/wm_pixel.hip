@@ -312,7 +312,7 @@ inline unsigned grid_for(size_t work_items, unsigned block = 256, unsigned cap =
 
 int color_dispatch(wm_ctx* ctx, int op, const uint8_t* in3, const uint8_t* plane_in, uint8_t* out3,
                    uint8_t* plane_out, size_t n_px) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n_px == 0) return WM_OK;
   if (!in3) return set_err(WM_ERR_BADARG, "input is NULL");
   if ((((uintptr_t)in3 | (uintptr_t)plane_in | (uintptr_t)out3 | (uintptr_t)plane_out) & 15u) != 0)
@@ -365,6 +365,7 @@ int wm_replace_y_u8_dev(wm_ctx* ctx, const uint8_t* bgr, const uint8_t* y_new, u
 // sum of squared differences (device scalar, exact integer); psnr = 20 log10(255 / sqrt(ssd / n))
 int wm_sqdiff_u8_dev(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, unsigned long long* ssd_dev) {
   if (!ctx || !ssd_dev) return set_err(WM_ERR_BADARG, "NULL argument");
+  WM_TRY(wmi::use_ctx(ctx));
   WM_HIP(hipMemsetAsync(ssd_dev, 0, sizeof(unsigned long long), ctx->stream));
   if (n == 0) return WM_OK;
   if (!a || !b || (((uintptr_t)a | (uintptr_t)b) & 15u)) return set_err(WM_ERR_BADARG, "buffers must be non-NULL and 16-byte aligned");
@@ -377,6 +378,7 @@ int wm_sqdiff_u8_dev(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, 
 int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2, size_t stride2, int H, int W,
                 int kind, double* ssim_dev) {
   if (!ctx || !img1 || !img2 || !ssim_dev) return set_err(WM_ERR_BADARG, "NULL argument");
+  WM_TRY(wmi::use_ctx(ctx));
   if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
   const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST), block(256);
   const size_t nblk = (size_t)grid.x * grid.y;
@@ -396,7 +398,7 @@ int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2,
 
 // out = uint8(clip(normalize_minmax(x), 0, 255))  (or just the clip when do_norm == 0)
 int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint8_t* out) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n == 0) return WM_OK;
   if (!x || !out) return set_err(WM_ERR_BADARG, "NULL argument");
   if (((uintptr_t)x & 15u) != 0) return set_err(WM_ERR_BADARG, "float plane must be 16-byte aligned");
@@ -419,7 +421,7 @@ static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 int wm_color_u8(wm_ctx* ctx, int op, const uint8_t* in3, const uint8_t* plane_in, uint8_t* out3, uint8_t* plane_out,
                 size_t n_px) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (op < 0 || op > 4) return set_err(WM_ERR_BADARG, "unknown colour op");
   if (n_px == 0) return WM_OK;
   char* b;
@@ -446,6 +448,7 @@ int wm_color_u8(wm_ctx* ctx, int op, const uint8_t* in3, const uint8_t* plane_in
 
 int wm_psnr_u8(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double* psnr_out) {
   if (!ctx || !psnr_out) return set_err(WM_ERR_BADARG, "NULL argument");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n == 0) { *psnr_out = 99.0; return WM_OK; }
   if (!a || !b) return set_err(WM_ERR_BADARG, "NULL argument");
   char* base;
@@ -466,6 +469,7 @@ int wm_psnr_u8(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, double
 
 int wm_ssim(wm_ctx* ctx, const void* img1, const void* img2, int H, int W, int kind, double* ssim_out) {
   if (!ctx || !img1 || !img2 || !ssim_out) return set_err(WM_ERR_BADARG, "NULL argument");
+  WM_TRY(wmi::use_ctx(ctx));
   if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
   const size_t n = (size_t)H * W;
   const size_t b1 = n * ((kind & 1) ? 4 : 1), b2 = n * ((kind & 2) ? 4 : 1);
@@ -483,7 +487,7 @@ int wm_ssim(wm_ctx* ctx, const void* img1, const void* img2, int H, int W, int k
 }
 
 int wm_normalize_u8(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint8_t* out) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n == 0) return WM_OK;
   if (!x || !out) return set_err(WM_ERR_BADARG, "NULL argument");
   char* base;

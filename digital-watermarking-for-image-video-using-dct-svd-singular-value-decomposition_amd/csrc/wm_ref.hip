@@ -660,7 +660,7 @@ void sort_sigma(const RefPlan& p, const double* b2, const double* q2, std::vecto
 }
 
 int check_ref_args(wm_ctx* ctx, const void* plane, int n_planes, int H, int W, int row_stride, size_t plane_stride) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
   if (n_planes <= 0 || n_planes > 65535) return set_err(WM_ERR_BADARG, "n_planes must be in 1..65535");
   if (!plane) return set_err(WM_ERR_BADARG, "plane pointer is NULL");

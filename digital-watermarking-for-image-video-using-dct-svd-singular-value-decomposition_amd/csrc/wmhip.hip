@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_detect_finalize(const double* __restric
 // ---------------------------------------------------------------------------
 int check_plane_args(const wm_ctx* ctx, const void* p, int n_planes, int H, int W, int row_stride,
                      size_t plane_stride) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n_planes < 0 || H < 0 || W < 0) return set_err(WM_ERR_BADARG, "negative size");
   if (!p && n_planes > 0 && H > 0 && W > 0) return set_err(WM_ERR_BADARG, "plane pointer is NULL");
   if (n_planes > 65535) return set_err(WM_ERR_BADARG, "n_planes > 65535");
@@ -614,13 +614,13 @@ int wm_destroy(wm_ctx* ctx) {
 }
 
 int wm_sync(wm_ctx* ctx) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   WM_HIP(hipStreamSynchronize(ctx->stream));
   return WM_OK;
 }
 
 int wm_check_status(wm_ctx* ctx) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   int st = 0;
   WM_HIP(hipMemcpyAsync(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -643,7 +643,7 @@ int wm_malloc(wm_ctx* ctx, size_t bytes, void** dptr_out) {
 }
 
 int wm_free(wm_ctx* ctx, void* dptr) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (dptr) { WM_HIP(hipStreamSynchronize(ctx->stream)); WM_HIP(hipFree(dptr)); }
   return WM_OK;
 }
@@ -818,7 +818,7 @@ int wm_extract_tiles_px_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* s
 
 int wm_tile_factors_to_pixel_dev(wm_ctx* ctx, const float* Uw, const float* Vwt, float* Ux, float* Vxt,
                                  size_t n_tiles) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n_tiles == 0) return WM_OK;
   if (!Uw || !Vwt || !Ux || !Vxt || (((uintptr_t)Uw | (uintptr_t)Vwt | (uintptr_t)Ux | (uintptr_t)Vxt) & 15u))
     return set_err(WM_ERR_BADARG, "factor arrays are NULL or not 16-byte aligned");
@@ -832,7 +832,7 @@ int wm_tile_factors_to_pixel_dev(wm_ctx* ctx, const float* Uw, const float* Vwt,
 // ---- K4 --------------------------------------------------------------------
 int wm_reconstruct_tiles_dev(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,
                              float* out, int n_planes, int H, int W) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n_planes < 0 || H < 0 || W < 0 || n_planes > 65535) return set_err(WM_ERR_BADARG, "bad size");
   if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
   if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
@@ -996,7 +996,7 @@ int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
 
 int wm_reconstruct_tiles(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,
                          float* out, int n_planes, int H, int W) {
-  if (!ctx) return set_err(WM_ERR_BADARG, "ctx is NULL");
+  WM_TRY(wmi::use_ctx(ctx));
   if (n_planes < 0 || H < 0 || W < 0) return set_err(WM_ERR_BADARG, "negative size");
   if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
   if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
