@@ -521,9 +521,13 @@ WM_HD void add_completion(float (&a)[8][8], const float scale) {
 // ---- packed one-sided Jacobi WITH V: A and V stacked as one 16-row matrix ----
 // The same rotation (jacobi_rot_pk's two-rsq angle) is applied to the 4 row pairs
 // of A and the 4 row pairs of V; dot products and norms come from the A half only.
+// `active` = false freezes the lane: the rotation becomes the exact identity (cos 1, sin 0),
+// so a tile that has converged is not touched by the extra sweeps its wave neighbours need.
+// The fallback kernel groups tiles in the (atomic, run-to-run varying) order of its work list;
+// with the freeze a tile's result does not depend on which tiles share its wave.
 template <int CHECK>
 WM_HD void jacobi_rot_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], const int p, const int q,
-                           bool& notconv) {
+                           bool& notconv, const bool active) {
   v2f gv = a[0][p] * a[0][q];
 #pragma unroll
   for (int rp = 1; rp < 4; ++rp) gv = fma2(a[rp][p], a[rp][q], gv);
@@ -539,10 +543,10 @@ WM_HD void jacobi_rot_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], const
   const float c0 = x * rx;
   const float s0 = (g * ih) * rx;
   const bool sw = tau > 0.0f;
-  const float C = sw ? s0 : c0, Sn = sw ? c0 : s0;
-  const float w = fabsf((s0 * rx) * g);
-  n2[p] = fmaxf(al, be) + w;
-  n2[q] = fminf(al, be) - w;
+  const float C = active ? (sw ? s0 : c0) : 1.0f, Sn = active ? (sw ? c0 : s0) : 0.0f;
+  const float w = active ? fabsf((s0 * rx) * g) : 0.0f;
+  n2[p] = active ? fmaxf(al, be) + w : al;
+  n2[q] = active ? fminf(al, be) - w : be;
   const v2f Cv = splat2(C), Sv = splat2(Sn);
 #pragma unroll
   for (int rp = 0; rp < 4; ++rp) {
@@ -571,16 +575,17 @@ WM_HD int jacobi_cols_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], float
       v[rp][c] = e;
     }
   int sweep = 0;
-  bool more = true;
+  bool more = true, active = true;
   while (more && sweep < JAC_MAX_SWEEPS) {
     col_norms2_pk(a, n2);
     bool notconv = false;
 #pragma unroll
     for (int p = 0; p < 7; ++p)
 #pragma unroll
-      for (int q = p + 1; q < 8; ++q) jacobi_rot_pk_v<1>(a, v, n2, p, q, notconv);
+      for (int q = p + 1; q < 8; ++q) jacobi_rot_pk_v<1>(a, v, n2, p, q, notconv, active);
     ++sweep;
-    more = wave_any(notconv);
+    active = active && notconv;        // this tile is done once one of its own sweeps saw nothing to rotate
+    more = wave_any(active);
   }
   col_norms2_pk(a, n2);
   col_norms2_pk(v, vn2);

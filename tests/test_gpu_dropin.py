@@ -204,3 +204,29 @@ def test_fullframe_golden_fixture_through_the_dropin(core, path):
         assert ok and abs(score - float(g["detect_score"])) < 5e-3
         with pytest.raises(ValueError, match="Sai mật khẩu"):
             core.extract_arrays(g["stego"], gm, "wrong")
+
+
+def test_config4_256_frames_1080p_sharded_equals_unsharded(gpu_ctx, pkg):
+    """BASELINE config 4 at full size: 256 frames 1080x1920, rank r of 8 takes frames
+    [r*256//8, (r+1)*256//8).  Property: the ranks' shares tile the batch and are bit-identical
+    to the unsharded run; two frames are checked against the oracle on a crop of full tiles."""
+    import importlib
+    v = importlib.import_module(pkg.__name__ + ".video")
+    sh = importlib.import_module(pkg.__name__ + ".sharding")
+    N, H, W, alpha = 256, 1080, 1920, 0.15
+    rng = np.random.default_rng(1234)
+    frames = rng.integers(0, 256, (N, H, W), dtype=np.uint8)
+    wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+    Uw, Sw, Vwt = gpu_ctx.svd_tiles(wys)
+    st_all, sc_all = v.embed_frames(gpu_ctx, frames, Sw, alpha, 8, batch=32)
+    covered = []
+    for r in range(8):
+        (lo, hi), st, sc = v.embed_frames_sharded(gpu_ctx, frames, Sw, alpha, 8, rank=r, world_size=8, batch=32)
+        assert (lo, hi) == sh.frame_range(r, 8, N) == (32 * r, 32 * r + 32)
+        assert np.array_equal(st, st_all[lo:hi]) and np.array_equal(sc, sc_all[lo:hi])
+        covered.extend(range(lo, hi))
+    assert covered == list(range(N))
+    for i in (0, 255):
+        ref = o.embed_plane(frames[i, :64, :128].astype(np.float32), wys[:64, :128], alpha, 0.0, 8, k_floor=8)
+        assert np.abs(st_all[i, :64, :128].astype(int) - ref["stego"].astype(int)).max() <= 1
+    assert 20 < o.psnr(frames[7], st_all[7]) < 30

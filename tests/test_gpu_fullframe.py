@@ -1,5 +1,8 @@
 """GPU parity of the full-frame mode (tile=None, the reference's own semantics)
-against the oracle: singular values 1e-4 relative (to sigma_1), stego 1 LSB."""
+against the oracle: singular values 2e-6 relative to sigma_1 (the oracle itself rounds its
+float64 LAPACK values to float32; the GPU values are measured on the untouched input, so the
+scale drift of the rotated rows - 3e-5..3e-4 before that fix - cannot come back unnoticed),
+stego 1 LSB."""
 import numpy as np
 import pytest
 
@@ -23,13 +26,15 @@ def test_fullframe_embed_sigma_detect(gpu_ctx, H, W):
     ref = o.embed_plane(host.astype(np.float32), wys, alpha, kfrac, tile=None)
     L = min(H, W); K = ref["K"]
     stego, sc, yw = gpu_ctx.ref_embed(host, ref["Sw"], alpha, K, want_yw=True)
-    assert np.max(np.abs(sc - ref["Sc"])) / ref["Sc"][0] < 1e-4
+    assert np.max(np.abs(sc - ref["Sc"])) / ref["Sc"][0] < 2e-6
     d = np.abs(stego.astype(int) - ref["stego"].astype(int))
     assert d.max() <= 1 and np.mean(d != 0) < 2e-3
     assert np.abs(yw - ref["Yw"]).max() < 2e-2
     s = gpu_ctx.ref_sigma(ref["stego"])
     so = o.stego_sigma(ref["stego"].astype(np.float32), None)
-    assert np.max(np.abs(s - so)) / so[0] < 1e-4
+    assert np.max(np.abs(s - so)) / so[0] < 2e-6
+    big = so > 1e-3 * so[0]
+    assert np.max(np.abs(s - so)[big] / so[big]) < 2e-5          # and per value, not only against sigma_1
     score = gpu_ctx.ref_detect(ref["stego"], ref["Sc"], ref["Sw"], alpha)
     assert abs(score - o.detect_plane(ref["stego"].astype(np.float32), ref["Sc"], ref["Sw"], alpha, None)) < 2e-3
 
