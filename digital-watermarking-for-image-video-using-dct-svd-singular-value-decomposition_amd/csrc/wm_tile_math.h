@@ -257,6 +257,31 @@ WM_HD v2f fma2(v2f a, v2f b, v2f c) {
 #endif
 }
 
+// acc + (ab[HALF], ab[HALF]) * x  and  (ab[HALF], ab[HALF]) * x : the broadcast is the packed
+// instruction's op_sel, written out so that the compiler cannot materialise (and then hoist and
+// spill) the 64 broadcast pairs of B the embed epilogue reads.
+template <int HALF>
+WM_HD v2f fma2_bcast(const v2f ab, const v2f x, v2f acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (HALF == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(ab), "v"(x));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(ab), "v"(x));
+  return acc;
+#else
+  return fma2(splat2(ab[HALF]), x, acc);
+#endif
+}
+template <int HALF>
+WM_HD v2f mul2_bcast(const v2f ab, const v2f x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v2f r;
+  if (HALF == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(ab), "v"(x));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(ab), "v"(x));
+  return r;
+#else
+  return splat2(ab[HALF]) * x;
+#endif
+}
+
 constexpr float SIGMA_RATIO_MIN2 = 1e-10f;   // (s_8 / s_1)^2 below this -> literal path
 
 // one Jacobi rotation of columns p,q (no V).  c0 = cos, s0 = sin*sign(g) from
@@ -385,57 +410,74 @@ WM_HD int embed_jacobi_pk(const RawTile& t, v2f (&a)[4][8], float (&n2)[8]) {
   return jacobi_cols_pk(a, n2);
 }
 
-// Phase 2: singular values out, perturbation, Y = X + B diag(e) B^T X, quantise.
-// The kernel reloads the raw tile and loads sw only now, so nothing but B has
-// to stay live across the sweep loop.
-template <bool YW>
-WM_HD void embed_finish_pk(const RawTile& t, const v2f (&a)[4][8], const float (&n2)[8],
-                           const float (&sw)[8], const float (&alpha_k)[8], float (&sc)[8],
-                           RawTile& out, float* yw, const size_t yw_stride, bool& deficient) {
+// Phase 2a: singular values out, e_i = alpha_i sw_i / s_i^3, rank-deficiency flag.
+WM_HD void embed_coeffs_pk(const float (&n2)[8], const float (&sw)[8], const float (&alpha_k)[8],
+                           float (&e)[8], float (&sc)[8], bool& deficient) {
   deficient = !(n2[7] > SIGMA_RATIO_MIN2 * n2[0]);
-  float e[8];                                        // alpha_i sw_i / s_i^3
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float rs = frsq(fmaxf(n2[i], 1e-30f));
     sc[i] = n2[i] * rs;
     e[i] = (alpha_k[i] * sw[i]) * (rs * rs * rs);
   }
-  // Y = X + B G with G = diag(e) (B^T X), one column pair (2 of the 8 columns)
-  // at a time so that only 8 packed registers of G are live next to B:
-  // g[i] = (G[i][2cp], G[i][2cp+1]);  b_i[r] is one half of a[r>>1][i],
-  // broadcast by the packed FMA's op_sel.
+}
+
+// Phase 2b: four columns of Y = X + B G, G = diag(e) (B^T X), from the eight row words `w`
+// (little-endian bytes = the four pixels of each row in this half), one column pair at a time
+// so that only 8 packed registers of G are live next to B:  g[i] = (G[i][c], G[i][c+1]);
+// b_i[r] is one half of a[r>>1][i], broadcast by the packed FMA's op_sel.  Columns of X only
+// enter their own columns of Y, so the two halves of a tile are independent (the kernel loads,
+// finishes and stores them one after the other to stay within 128 VGPRs).
+// outw: quantised stego bytes; with YW the unclipped floats go to yw[r * yw_stride + 0..3].
+template <bool YW>
+WM_HD void embed_half_pk(const uint32_t (&w)[8], const v2f (&a)[4][8], const float (&e)[8],
+                         uint32_t (&outw)[8], float* yw, const size_t yw_stride) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) { out.lo[r] = 0u; out.hi[r] = 0u; }
+  for (int r = 0; r < 8; ++r) outw[r] = 0u;
 #pragma unroll
-  for (int cp = 0; cp < 4; ++cp) {
-    const int sh = 16 * (cp & 1);
+  for (int cp = 0; cp < 2; ++cp) {
+    const int sh = 16 * cp;
     v2f g[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t w = ((cp < 2) ? t.lo[r] : t.hi[r]) >> sh;
-      const v2f x = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
+      const uint32_t ww = w[r] >> sh;
+      const v2f x = {(float)(ww & 0xffu), (float)((ww >> 8) & 0xffu)};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const v2f b = splat2(a[r >> 1][i][r & 1]);
-        g[i] = (r == 0) ? b * x : fma2(b, x, g[i]);
+        const v2f ab = a[r >> 1][i];
+        if (r == 0) g[i] = mul2_bcast<0>(ab, x);
+        else g[i] = (r & 1) ? fma2_bcast<1>(ab, x, g[i]) : fma2_bcast<0>(ab, x, g[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) g[i] = g[i] * splat2(e[i]);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t w = ((cp < 2) ? t.lo[r] : t.hi[r]) >> sh;
-      v2f y = {(float)(w & 0xffu), (float)((w >> 8) & 0xffu)};
+      const uint32_t ww = w[r] >> sh;
+      v2f y = {(float)(ww & 0xffu), (float)((ww >> 8) & 0xffu)};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) y = fma2(splat2(a[r >> 1][i][r & 1]), g[i], y);
+      for (int i = 0; i < 8; ++i) {
+        const v2f ab = a[r >> 1][i];
+        y = (r & 1) ? fma2_bcast<1>(ab, g[i], y) : fma2_bcast<0>(ab, g[i], y);
+      }
       if (YW) {
         float* o = yw + (size_t)r * yw_stride + 2 * cp;
         o[0] = y[0]; o[1] = y[1];
       }
-      const uint32_t q = (quant_u8(y[0]) | (quant_u8(y[1]) << 8)) << sh;
-      if (cp < 2) out.lo[r] |= q; else out.hi[r] |= q;
+      outw[r] |= (quant_u8(y[0]) | (quant_u8(y[1]) << 8)) << sh;
     }
   }
+}
+
+// Phase 2 in one piece (CPU harness / simple callers): the raw tile in, the stego tile out.
+template <bool YW>
+WM_HD void embed_finish_pk(const RawTile& t, const v2f (&a)[4][8], const float (&n2)[8],
+                           const float (&sw)[8], const float (&alpha_k)[8], float (&sc)[8],
+                           RawTile& out, float* yw, const size_t yw_stride, bool& deficient) {
+  float e[8];
+  embed_coeffs_pk(n2, sw, alpha_k, e, sc, deficient);
+  embed_half_pk<YW>(t.lo, a, e, out.lo, yw, yw_stride);
+  embed_half_pk<YW>(t.hi, a, e, out.hi, YW ? yw + 4 : nullptr, yw_stride);
 }
 
 // both phases back to back (CPU harness / simple callers)
@@ -521,13 +563,9 @@ WM_HD void add_completion(float (&a)[8][8], const float scale) {
 // ---- packed one-sided Jacobi WITH V: A and V stacked as one 16-row matrix ----
 // The same rotation (jacobi_rot_pk's two-rsq angle) is applied to the 4 row pairs
 // of A and the 4 row pairs of V; dot products and norms come from the A half only.
-// `active` = false freezes the lane: the rotation becomes the exact identity (cos 1, sin 0),
-// so a tile that has converged is not touched by the extra sweeps its wave neighbours need.
-// The fallback kernel groups tiles in the (atomic, run-to-run varying) order of its work list;
-// with the freeze a tile's result does not depend on which tiles share its wave.
 template <int CHECK>
 WM_HD void jacobi_rot_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], const int p, const int q,
-                           bool& notconv, const bool active) {
+                           bool& notconv) {
   v2f gv = a[0][p] * a[0][q];
 #pragma unroll
   for (int rp = 1; rp < 4; ++rp) gv = fma2(a[rp][p], a[rp][q], gv);
@@ -543,10 +581,10 @@ WM_HD void jacobi_rot_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], const
   const float c0 = x * rx;
   const float s0 = (g * ih) * rx;
   const bool sw = tau > 0.0f;
-  const float C = active ? (sw ? s0 : c0) : 1.0f, Sn = active ? (sw ? c0 : s0) : 0.0f;
-  const float w = active ? fabsf((s0 * rx) * g) : 0.0f;
-  n2[p] = active ? fmaxf(al, be) + w : al;
-  n2[q] = active ? fminf(al, be) - w : be;
+  const float C = sw ? s0 : c0, Sn = sw ? c0 : s0;
+  const float w = fabsf((s0 * rx) * g);
+  n2[p] = fmaxf(al, be) + w;
+  n2[q] = fminf(al, be) - w;
   const v2f Cv = splat2(C), Sv = splat2(Sn);
 #pragma unroll
   for (int rp = 0; rp < 4; ++rp) {
@@ -574,17 +612,23 @@ WM_HD int jacobi_cols_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], float
       v2f e = {(2 * rp == c) ? 1.0f : 0.0f, (2 * rp + 1 == c) ? 1.0f : 0.0f};
       v[rp][c] = e;
     }
+  // A tile that has converged (one of its own sweeps saw nothing to rotate) is frozen: its lane
+  // sits out (exec mask) the extra sweeps its wave neighbours need.  The fallback kernel groups
+  // tiles in the (atomic, run-to-run varying) order of its work list; with the freeze a tile's
+  // result does not depend on which tiles share its wave.
   int sweep = 0;
   bool more = true, active = true;
   while (more && sweep < JAC_MAX_SWEEPS) {
-    col_norms2_pk(a, n2);
-    bool notconv = false;
+    if (active) {
+      col_norms2_pk(a, n2);
+      bool notconv = false;
 #pragma unroll
-    for (int p = 0; p < 7; ++p)
+      for (int p = 0; p < 7; ++p)
 #pragma unroll
-      for (int q = p + 1; q < 8; ++q) jacobi_rot_pk_v<1>(a, v, n2, p, q, notconv, active);
+        for (int q = p + 1; q < 8; ++q) jacobi_rot_pk_v<1>(a, v, n2, p, q, notconv);
+      active = notconv;
+    }
     ++sweep;
-    active = active && notconv;        // this tile is done once one of its own sweeps saw nothing to rotate
     more = wave_any(active);
   }
   col_norms2_pk(a, n2);

@@ -116,6 +116,29 @@ __device__ __forceinline__ void load_raw(const uint8_t* __restrict__ p, const si
   }
 }
 
+// one 4-pixel word per row (half a tile)
+template <bool ALIGNED>
+__device__ __forceinline__ void load_words(const uint8_t* __restrict__ p, const size_t stride, uint32_t (&w)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint8_t* q = p + r * stride;
+    if (ALIGNED) w[r] = *reinterpret_cast<const uint32_t*>(q);
+    else w[r] = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+  }
+}
+template <bool ALIGNED>
+__device__ __forceinline__ void store_words(uint8_t* __restrict__ p, const size_t stride, const uint32_t (&w)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    uint8_t* q = p + r * stride;
+    if (ALIGNED) *reinterpret_cast<uint32_t*>(q) = w[r];
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = (uint8_t)(w[r] >> (8 * i));
+    }
+  }
+}
+
 template <bool ALIGNED>
 __device__ __forceinline__ void store_raw(uint8_t* __restrict__ p, const size_t stride,
                                           const wm::RawTile& t) {
@@ -210,18 +233,23 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
     load_raw<ALIGNED>(host + off, g.row_stride, raw);
     sweeps = wm::embed_jacobi_pk(raw, a, n2);
   }
-  // Only B (64 VGPRs) crosses the sweep loop: the raw tile is re-read (L2) and
-  // the watermark sigma loaded only now, instead of being spilled to scratch.
+  // Only B (64 VGPRs) crosses the sweep loop; everything else is (re)loaded when it is used
+  // and stored as soon as it is final, so that the kernel fits 128 VGPRs (4 waves per SIMD):
+  // watermark sigma -> coefficients -> Sc out; then the two 4-column halves of the tile one
+  // after the other, each re-reading its row words (L2) and writing its stego words.
   asm volatile("" ::: "memory");
-  wm::RawTile raw, out;
-  float sw[8], sc[8], alpha_k[8];
-  load_raw<ALIGNED>(host + off, g.row_stride, raw);
-  load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
-  float* ywp = YW ? yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8 : nullptr;
+  float e[8];
   bool deficient;
-  wm::embed_finish_pk<YW>(raw, a, n2, sw, alpha_k, sc, out, ywp, (size_t)g.W, deficient);
+  {
+    float sw[8], sc[8], alpha_k[8];
+    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
+    wm::embed_coeffs_pk(n2, sw, alpha_k, e, sc, deficient);
+    // flagged tiles are left untouched: stego may alias host (in-place embedding) and the
+    // fallback kernel must still read the original pixels; it also writes their Sc
+    if (!deficient) store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
+  }
   // deficient tiles are appended (wave-aggregated) to the fallback list
   const unsigned long long dmask = __builtin_amdgcn_ballot_w64(deficient);
   if (dmask != 0ull) {
@@ -236,11 +264,14 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
     }
   }
   if (sweeps < 0) atomicOr(status, 1);
-  // flagged tiles are left untouched: stego may alias host (in-place embedding) and the
-  // fallback kernel must still read the original pixels
-  if (!deficient) {
-    store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
-    store_raw<ALIGNED>(stego + off, g.row_stride, out);
+  float* ywp = YW ? yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8 : nullptr;
+#pragma nounroll
+  for (int half = 0; half < 2; ++half) {      // a real loop: one half's registers at a time
+    uint32_t w[8], ow[8];
+    load_words<ALIGNED>(host + off + 4 * half, g.row_stride, w);
+    wm::embed_half_pk<YW>(w, a, e, ow, YW ? ywp + 4 * half : nullptr, (size_t)g.W);
+    if (!deficient) store_words<ALIGNED>(stego + off + 4 * half, g.row_stride, ow);
+    asm volatile("" ::: "memory");
   }
 }
 
