@@ -730,7 +730,7 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
     const bool al = u8_aligned(host, stego, row_stride, plane_stride);
     const dim3 grid = tile_grid(g, n_planes), block(WAVE);
     const size_t n_all = (size_t)g.n_tiles * (size_t)n_planes;
-    if (n_all > 0xffffffffull) return set_err(WM_ERR_BADARG, "more than 2^32 tiles in one call");
+    if (n_all > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 tiles in one call");   // ids are uint32, the device-side count an int
     const size_t n_waves = (n_all + WAVE - 1) / WAVE;
     WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, n_all * sizeof(uint32_t), "fallback list"));
     WM_HIP(hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int), ctx->stream));
