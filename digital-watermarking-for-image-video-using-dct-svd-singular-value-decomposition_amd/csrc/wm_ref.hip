@@ -545,12 +545,13 @@ int upload_pairs(wm_ctx* ctx, const RefPlan& p, const RefWs& w) {
   return WM_OK;
 }
 
-// orthonormal DCT-II basis D_n (float64 on the host, rounded to float32), cached per context
-int get_dct(wm_ctx* ctx, int n, int slot, float** out) {
-  if (ctx->dct_n[slot] == n && ctx->dct_mat[slot]) { *out = ctx->dct_mat[slot]; return WM_OK; }
-  const int other = 1 - slot;
-  if (ctx->dct_n[other] == n && ctx->dct_mat[other]) { *out = ctx->dct_mat[other]; return WM_OK; }
-  if (ctx->dct_mat[slot]) { WM_HIP(hipStreamSynchronize(ctx->stream)); WM_HIP(hipFree(ctx->dct_mat[slot])); ctx->dct_mat[slot] = nullptr; ctx->dct_n[slot] = 0; }
+// orthonormal DCT-II basis D_n (float64 on the host, rounded to float32) into cache slot `slot`
+int fill_dct(wm_ctx* ctx, int n, int slot) {
+  if (ctx->dct_mat[slot]) {
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    WM_HIP(hipFree(ctx->dct_mat[slot]));
+    ctx->dct_mat[slot] = nullptr; ctx->dct_n[slot] = 0;
+  }
   if (hipMalloc((void**)&ctx->dct_mat[slot], (size_t)n * n * 4) != hipSuccess) {
     (void)hipGetLastError();
     return set_err(WM_ERR_NOMEM, "hipMalloc failed for %s", "DCT basis");
@@ -564,7 +565,30 @@ int get_dct(wm_ctx* ctx, int n, int slot, float** out) {
   WM_HIP(hipMemcpyAsync(ctx->dct_mat[slot], D.data(), D.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
   ctx->dct_n[slot] = n;
-  *out = ctx->dct_mat[slot];
+  return WM_OK;
+}
+
+// D_H and D_W of one plane, from the two-slot per-context cache.  Both are resolved in ONE
+// call: a slot that already holds one of the two sizes is never the one evicted for the other
+// (fetching them one after the other could free the matrix just handed out - found by the
+// re-entrancy test, which ran 96x128 on a context whose cache held 64 and 96).
+int get_dct_pair(wm_ctx* ctx, int H, int W, float** dH, float** dW) {
+  int sh = -1, sw = -1;
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->dct_mat[i] && ctx->dct_n[i] == H && sh < 0) sh = i;
+    if (ctx->dct_mat[i] && ctx->dct_n[i] == W && sw < 0) sw = i;
+  }
+  if (sh < 0) {
+    sh = (sw == 0) ? 1 : 0;                      // any slot that does not hold W
+    WM_TRY(fill_dct(ctx, H, sh));
+    if (H == W) sw = sh;
+  }
+  if (sw < 0) {
+    sw = 1 - sh;                                 // the slot that does not hold H
+    WM_TRY(fill_dct(ctx, W, sw));
+  }
+  *dH = ctx->dct_mat[sh];
+  *dW = ctx->dct_mat[sw];
   return WM_OK;
 }
 
@@ -841,8 +865,7 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
   const float* src = d_in; size_t src_stride = (size_t)row_stride;
   if (apply_dct) {
     float *dH, *dW;
-    WM_TRY(get_dct(ctx, H, 0, &dH));
-    WM_TRY(get_dct(ctx, W, 1, &dW));
+    WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
     WM_TRY(sgemm(ctx, false, false, H, W, H, 1.0f, dH, H, d_in, row_stride, 0.0f, w.tmp2, W));   // D_H X
     WM_TRY(sgemm(ctx, false, true, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_c, W));              // (D_H X) D_W^T
     src = d_c; src_stride = (size_t)W;
@@ -910,8 +933,7 @@ int wm_ref_extract_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sig
   WM_HIP(hipMemcpyAsync(d_u, Uw, (size_t)L * L * 4, hipMemcpyHostToDevice, ctx->stream));            // Uw[:L,:L] (H x L, rows < L)
   WM_HIP(hipMemcpyAsync(d_v, vv.data(), vv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   float *dH, *dW;
-  WM_TRY(get_dct(ctx, H, 0, &dH));
-  WM_TRY(get_dct(ctx, W, 1, &dW));
+  WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
   std::vector<float> sh((size_t)p.Lp, 0.0f);
   for (int z = 0; z < n_planes; ++z) {
     std::fill(sh.begin(), sh.end(), 0.0f);

@@ -28,6 +28,7 @@ BASELINE.json's north_star uses).
 from __future__ import annotations
 
 import os
+import threading
 from typing import Optional
 
 import numpy as np
@@ -38,13 +39,19 @@ from . import hostglue as hg
 K_FRAC_DEFAULT = hg.K_FRAC_DEFAULT
 TILE = 8
 
-_contexts = {}
+_tls = threading.local()
 
 
 def _ctx(device: int = 0) -> hostapi.Context:
-    c = _contexts.get(device)
+    """One cached context per (calling thread, device): a context owns its stream and grow-only
+    scratch buffers, so two threads inside embed()/extract() at once must not share one (the
+    reference's functions are re-entrant).  Released when the thread ends."""
+    cache = getattr(_tls, "contexts", None)
+    if cache is None:
+        cache = _tls.contexts = {}
+    c = cache.get(device)
     if c is None:
-        c = _contexts[device] = hostapi.Context(device)
+        c = cache[device] = hostapi.Context(device)
     return c
 
 

@@ -230,3 +230,31 @@ def test_config4_256_frames_1080p_sharded_equals_unsharded(gpu_ctx, pkg):
         ref = o.embed_plane(frames[i, :64, :128].astype(np.float32), wys[:64, :128], alpha, 0.0, 8, k_floor=8)
         assert np.abs(st_all[i, :64, :128].astype(int) - ref["stego"].astype(int)).max() <= 1
     assert 20 < o.psnr(frames[7], st_all[7]) < 30
+
+
+def test_dropin_is_reentrant_across_threads(core):
+    """Two threads inside embed_arrays()/extract_arrays() at the same time (the reference's
+    functions are plain re-entrant Python): each thread gets its own context, results equal
+    the single-threaded ones."""
+    import threading
+    rng = np.random.default_rng(8)
+    covers = [rng.integers(0, 256, (96, 128, 3), dtype=np.uint8) for _ in range(2)]
+    wm = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    want = [core.embed_arrays(c, wm, "pw", bytes(8), alpha=0.12, tile=t) for c, t in zip(covers, (8, None))]
+    got = [None, None]; errs = []
+
+    def work(i, tile):
+        try:
+            for _ in range(4):
+                got[i] = core.embed_arrays(covers[i], wm, "pw", bytes(8), alpha=0.12, tile=tile)
+                w = core.extract_arrays(got[i]["stego"], got[i]["meta"], "pw")
+                assert w.shape[:2] == (96, 128)
+        except Exception as e:             # surfaced below; a thread must not die silently
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i, t)) for i, t in enumerate((8, None))]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    for g, w in zip(got, want):
+        assert np.array_equal(g["stego"], w["stego"])
+        assert g["psnr"] == w["psnr"]

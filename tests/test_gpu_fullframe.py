@@ -103,3 +103,20 @@ def test_fullframe_batched_planes_equal_single(gpu_ctx):
     sig = gpu_ctx.ref_sigma_planes(st)
     for p in range(3):
         assert np.max(np.abs(sig[p] - gpu_ctx.ref_sigma(st[p]))) / sig[p, 0] < 1e-5
+
+
+def test_dct_basis_cache_survives_a_size_sequence(gpu_ctx):
+    """The per-context cache holds two DCT bases.  64x96 followed by 96x128 used to evict the
+    96 basis while it was the H basis of the second call (dangling pointer, wrong DCT of the
+    watermark).  Every call in a sequence of shapes must match the oracle."""
+    rng = np.random.default_rng(2)
+    for H, W in ((64, 96), (96, 128), (128, 96), (64, 64), (96, 64), (128, 128), (64, 96)):
+        wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+        U, S, Vt = gpu_ctx.ref_svd(wys, apply_dct=True)
+        C = o.dct2(wys)
+        assert np.abs(U @ np.diag(S) @ Vt - C).max() < 2e-4 * np.abs(C).max(), (H, W)
+        stego = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        sc = o.stego_sigma(stego.astype(np.float32), None) * 0.9
+        w = gpu_ctx.ref_extract(stego, sc, U, Vt, 0.15, min(H, W) // 2)
+        wo = o.extract_plane(stego.astype(np.float32), sc, U, Vt, 0.15, 0.5, H, W, None, k_floor=1)
+        assert np.abs(w - wo).max() < 3e-3 * np.abs(wo).max(), (H, W)
