@@ -39,6 +39,8 @@ constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to 
 // sigma-only calls (extract, detect): row norms are exact to O(cos^2), and the sweep that
 // observes max cos < c still rotates (leaving ~c^2), so they may stop an order earlier (2e-3 already costs 7e-5 relative on dense spectra: tools/ff_sigma_thr.py)
 constexpr float CONV_COS_SIGMA = 2e-4f;
+constexpr double DRIFT_TOL = 1e-2;        // |T[:, i]| / |b_i|^2 may differ from 1 by the scale drift, not more
+constexpr double NULL_ROW_RATIO = 1e-5;   // rows below this fraction of |A|_F do not take part in the convergence test
 constexpr double NULL_RATIO = 1e-6;   // embed: singular directions below this fraction of s_1 get no watermark energy
 
 // ---------------------------------------------------------------------------
@@ -198,7 +200,7 @@ constexpr int INNER_NW = INNER_NT / 64;
 
 __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__ partials, const int nch,
                                                       float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits,
-                                                      const int cross_only) {
+                                                      const float* __restrict__ floor2, const int cross_only) {
   __shared__ float GG[2][RP][RP + 1];   // double-buffered: a step reads one copy, writes the other
   float (*G)[RP + 1] = GG[0];
   __shared__ float R[RP][RP + 1];
@@ -209,6 +211,9 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
   Rout += (size_t)blockIdx.z * gridDim.x * RP * RP;
   maxcos_bits += blockIdx.z;
+  // rows whose squared norm is below this plane's floor are numerically null (rounding residue of
+  // a rank-deficient plane): their mutual cosines are O(1) noise and must not hold convergence up
+  const float fl2 = floor2[blockIdx.z];
   const float* src = partials + (size_t)p * nch * RP * RP;
   {
     // sum the column-chunk partials: independent loads in flight (4 elements x 4 chunks)
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   for (int e = t; e < RP * RP; e += INNER_NT) {
     const int r = e >> 6, c = e & 63;
     if (r != c) {
-      const float d = G[r][r] * G[c][c];
-      if (d > 0.0f) mx = fmaxf(mx, fabsf(G[r][c]) * __builtin_amdgcn_rsqf(d));
+      const float grr = G[r][r], gcc = G[c][c];
+      if (grr > fl2 && gcc > fl2) mx = fmaxf(mx, fabsf(G[r][c]) * __builtin_amdgcn_rsqf(grr * gcc));
     }
   }
 #pragma unroll
@@ -503,7 +508,7 @@ RefPlan make_plan(int H, int W, int B = 1) {
 }
 
 struct RefWs {           // carved out of ctx->ref_ws; every per-plane array is [B][...]
-  float* aug; float* partials; float* R; int2* pairs; unsigned* maxcos; double* b2; double* q2;
+  float* aug; float* partials; float* R; int2* pairs; unsigned* maxcos; float* floor2; double* b2; double* q2;
   float* dvec; int* order; float* scale; float* tmp1; float* tmp2;
 };
 
@@ -515,13 +520,13 @@ int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, 
   const size_t B = (size_t)p.B;
   const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * RP * RP * 4),
                o_R = take(B * p.npairs * RP * RP * 4), o_pairs = take((size_t)p.nsteps * p.npairs * sizeof(int2)),
-               o_mc = take(B * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
+               o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
                o_d = take(B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
                o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
   WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
   char* b = (char*)ctx->ref_ws;
   w.aug = (float*)(b + o_aug); w.partials = (float*)(b + o_par); w.R = (float*)(b + o_R);
-  w.pairs = (int2*)(b + o_pairs); w.maxcos = (unsigned*)(b + o_mc); w.b2 = (double*)(b + o_b2);
+  w.pairs = (int2*)(b + o_pairs); w.maxcos = (unsigned*)(b + o_mc); w.floor2 = (float*)(b + o_fl); w.b2 = (double*)(b + o_b2);
   w.q2 = (double*)(b + o_q2); w.dvec = (float*)(b + o_d); w.order = (int*)(b + o_ord);
   w.scale = (float*)(b + o_sc); w.tmp1 = (float*)(b + o_t1); w.tmp2 = (float*)(b + o_t2);
   return WM_OK;
@@ -615,6 +620,21 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
     WM_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     WM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }
+  // numerical-null floor per plane: (NULL_ROW_RATIO * |A|_F)^2 from the row norms of the loaded input
+  {
+    hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, 0, w.b2, w.q2);
+    std::vector<double> r2((size_t)p.B * p.Lp);
+    WM_HIP(hipMemcpyAsync(r2.data(), w.b2, r2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<float> fl(p.B);
+    for (int z = 0; z < p.B; ++z) {
+      double f2 = 0.0;
+      for (int i = 0; i < p.Lp; ++i) f2 += r2[(size_t)z * p.Lp + i];
+      fl[z] = (float)(NULL_ROW_RATIO * NULL_ROW_RATIO * f2);
+    }
+    WM_HIP(hipMemcpyAsync(w.floor2, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));       // fl is a local
+  }
   const size_t par_ps = (size_t)p.npairs * p.nch * RP * RP, r_ps = (size_t)p.npairs * RP * RP;
   auto step = [&](hipStream_t st, int z0, int nz, int s, int part) {
     const int2* pr = w.pairs + (size_t)s * p.npairs;
@@ -625,7 +645,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
       hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch, nz), dim3(256), 0, st, aug, p.aug_ps, p.ld, p.M, pr, par);
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
-                         (s == 0 || sweep < full_sweeps) ? 0 : 1);
+                         w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1);
       const int n_tiles = (ncols + 63) / 64;
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_tiles + p.apply_tiles - 1) / p.apply_tiles, nz), dim3(256), 0, st,
                          aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R);
@@ -683,7 +703,7 @@ int fetch_norms(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std:
 // b2^2 / |T[:, i]|^2 so that sqrt(b2 / q2) is s_i like in the [A | I] formulation.
 //   A0: dense [B][L][M] copy of the input rows;  T: dense [B][L][Lp] (left on the device).
 int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0, float* T, std::vector<double>& b2,
-                  std::vector<double>& q2) {
+                  std::vector<double>& q2, std::vector<unsigned char>* reliable = nullptr) {
   hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, 0, w.b2, w.q2);
   for (int z = 0; z < p.B; ++z)
     WM_TRY(sgemm(ctx, false, true, p.L, p.Lp, p.M, 1.0f, A0 + (size_t)z * p.L * p.M, p.M, w.aug + (size_t)z * p.aug_ps, p.ld,
@@ -694,9 +714,19 @@ int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0
   WM_HIP(hipMemcpyAsync(b2.data(), w.b2, b2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipMemcpyAsync(q2.data(), w.q2, q2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
+  // |T[:, i]| = |b_i| s_i must agree with |b_i|^2 up to the rotations' scale drift (a few 1e-4).
+  // A row that fails this is rounding residue of a rank-deficient plane - its direction is noise,
+  // A0 b_i^T measures nothing - and keeps its own (tiny) norm as singular value.
+  if (reliable) reliable->assign(b2.size(), 0);
   for (size_t i = 0; i < b2.size(); ++i) {
-    if (q2[i] > 0.0 && b2[i] > 0.0) q2[i] = b2[i] * b2[i] / q2[i];
-    else { b2[i] = 0.0; q2[i] = 1.0; }
+    const double t2 = q2[i];
+    if (t2 > 0.0 && b2[i] > 0.0) {
+      const double rho = sqrt(t2) / b2[i];
+      if (fabs(rho - 1.0) < DRIFT_TOL) {
+        q2[i] = b2[i] * b2[i] / t2;                                     // sigma = |T[:, i]| / |b_i|
+        if (reliable) (*reliable)[i] = 1;
+      } else q2[i] = 1.0;                                               // sigma = |b_i|
+    } else { b2[i] = 0.0; q2[i] = 1.0; }
   }
   return WM_OK;
 }
@@ -808,7 +838,8 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
   WM_TRY(jacobi_rows(ctx, p, w, false, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2;
-  WM_TRY(fetch_norms_t(ctx, p, w, d_yw, d_t, b2, q2));
+  std::vector<unsigned char> reliable;
+  WM_TRY(fetch_norms_t(ctx, p, w, d_yw, d_t, b2, q2, &reliable));
   // U diag(alpha Sw) V^T = T diag(e) B  with  e_i = alpha * sw[rank(i)] / (s_i |b_i|^2), rank < K
   // (u_i = T[:, i] / (|b_i| s_i), v_i^T = b_i / |b_i|;  S_[:K] = Sc[:K] + alpha*Sw[:K]).
   // Directions below NULL_RATIO * s_1 carry rounding noise instead of singular vectors: nothing is
@@ -824,7 +855,8 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
     for (int k = 0; k < std::min(K, p.L); ++k) {
       const int i = order[k];
       const double si = (double)sig[k];
-      d[(size_t)z * p.Lp + i] = (si > NULL_RATIO * s1 && pb[i] > 0.0) ? (float)((double)alpha * (double)sw[k] / (si * pb[i])) : 0.0f;
+      d[(size_t)z * p.Lp + i] = (reliable[(size_t)z * p.Lp + i] && si > NULL_RATIO * s1 && pb[i] > 0.0)
+                                    ? (float)((double)alpha * (double)sw[k] / (si * pb[i])) : 0.0f;
     }
   }
   WM_HIP(hipMemcpyAsync(w.dvec, d.data(), d.size() * 4, hipMemcpyHostToDevice, ctx->stream));

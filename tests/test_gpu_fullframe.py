@@ -120,3 +120,39 @@ def test_dct_basis_cache_survives_a_size_sequence(gpu_ctx):
         w = gpu_ctx.ref_extract(stego, sc, U, Vt, 0.15, min(H, W) // 2)
         wo = o.extract_plane(stego.astype(np.float32), sc, U, Vt, 0.15, 0.5, H, W, None, k_floor=1)
         assert np.abs(w - wo).max() < 3e-3 * np.abs(wo).max(), (H, W)
+
+
+def _rank_deficient_planes():
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (128, 72), dtype=np.uint8); a[:64] = a[:1, :1]            # half the plane constant
+    b = rng.integers(0, 256, (96, 160), dtype=np.uint8); b[20:60] = b[20]             # 40 equal rows
+    c = np.full((64, 64), 90, np.uint8)                                                # flat
+    d = rng.integers(0, 256, (200, 328), dtype=np.uint8); d[:30] = 16; d[-30:] = 16    # letterbox bars
+    return [a, b, c, d]
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_fullframe_rank_deficient_planes(gpu_ctx, idx):
+    """Flat areas, letterbox bars, repeated rows: the rotated null rows are rounding residue whose
+    mutual cosines never fall.  They must neither hold convergence up (this used to end in
+    'SVD did not converge') nor be mistaken for singular directions: sigma matches float64 LAPACK,
+    null values come out ~0, embed stays finite and matches the oracle where it is defined."""
+    x = _rank_deficient_planes()[idx]
+    H, W = x.shape
+    s = gpu_ctx.ref_sigma(x).astype(np.float64)
+    assert gpu_ctx.ref_last_sweeps() <= 20
+    ref = np.linalg.svd(x.astype(np.float64), compute_uv=False)
+    assert np.abs(s - ref).max() < 2e-6 * ref[0]
+    null = ref < 1e-9 * ref[0]
+    assert null.any() and s[null].max() < 1e-5 * ref[0]
+    Sw = np.sort(np.random.default_rng(1).uniform(10, 3000, min(H, W)).astype(np.float32))[::-1].copy()
+    K = int(0.6 * min(H, W))
+    st, sc, yw = gpu_ctx.ref_embed(x, Sw, 0.15, K, want_yw=True)
+    assert np.isfinite(yw).all() and np.abs(sc - ref).max() < 2e-6 * ref[0]
+    # oracle's own embed along the well-defined directions only (rank r): the GPU injects nothing below
+    # 1e-6 sigma_1, LAPACK's completion of the null space is arbitrary there
+    r = int((ref > 1e-6 * ref[0]).sum())
+    U, S, Vt = np.linalg.svd(x.astype(np.float64), full_matrices=False)
+    kk = min(K, r)
+    want = x.astype(np.float64) + (U[:, :kk] * (0.15 * Sw[:kk].astype(np.float64))) @ Vt[:kk]
+    assert np.abs(yw - want).max() < 5e-2
