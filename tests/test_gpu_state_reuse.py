@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(8, 8), (16, 40), (64, 96), (96, 64), (40, 40), (128, 72), (52, 83), (72, 128), (33, 17)]
+SHAPES = [(8, 8), (16, 40), (64, 96), (96, 64), (40, 40), (128, 72), (52, 83), (72, 128), (33, 17), (5, 20), (9, 7), (1, 1)]
 
 
 def _same(a, b):
@@ -64,3 +64,22 @@ def test_random_call_sequences_match_fresh_contexts(hostapi):
             assert _same(got, want), f"step {step}: op {op} on {n}x{H}x{W} differs from a fresh context"
     finally:
         long_lived.close()
+
+
+def test_identity_cases(gpu_ctx):
+    """alpha = 0 or K = 0 must return the host bytes unchanged, in both modes, also on ragged and
+    tiny planes (H or W below one tile: tile mode has nothing to do, full-frame still runs)."""
+    rng = np.random.default_rng(3)
+    for H, W in ((64, 96), (52, 83), (5, 20), (9, 7), (1, 1)):
+        x = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+        sw_t = np.abs(rng.normal(0, 100, (H // 8, W // 8, 8))).astype(np.float32)
+        for alpha, K in ((0.0, 8), (0.15, 0)):
+            st, sc, _ = gpu_ctx.embed_tiles(x, sw_t, alpha, K)
+            assert np.array_equal(st, x)
+        L = min(H, W)
+        sw_f = np.sort(np.abs(rng.normal(0, 1000, L)).astype(np.float32))[::-1].copy()
+        for alpha, K in ((0.0, L), (0.15, 0)):
+            st, sc, _ = gpu_ctx.ref_embed_planes(x, sw_f, alpha, K)
+            assert np.array_equal(st, x)
+            ref = np.linalg.svd(x[0].astype(np.float64), compute_uv=False)
+            assert np.abs(sc[0] - ref).max() <= 2e-6 * max(ref[0], 1.0)
