@@ -156,3 +156,25 @@ def test_fullframe_rank_deficient_planes(gpu_ctx, idx):
     kk = min(K, r)
     want = x.astype(np.float64) + (U[:, :kk] * (0.15 * Sw[:kk].astype(np.float64))) @ Vt[:kk]
     assert np.abs(yw - want).max() < 5e-2
+
+
+@pytest.mark.parametrize("noise", [2.0, 0.5])
+def test_fullframe_parity_on_smooth_content(gpu_ctx, noise):
+    """Camera-like plane (smooth field + sensor noise): singular values span 5+ decades.  The
+    values are compared per value (relative), the stego within 1 LSB of the float64 oracle."""
+    H, W, alpha = 256, 384, 0.15
+    rng = np.random.default_rng(12)
+    yy, xx = np.mgrid[0:H, 0:W]
+    field = 128 + 70 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + 40 * np.sin((xx + 2 * yy) / 91.0)
+    host = np.clip(field + rng.normal(0, noise, (H, W)), 0, 255).astype(np.uint8)
+    _, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, 0.6, tile=None)
+    stego, sc, yw = gpu_ctx.ref_embed(host, ref["Sw"], alpha, ref["K"], want_yw=True)
+    assert ref["Sc"][-1] < 1e-3 * ref["Sc"][0]                     # the spectrum really is steep
+    assert np.max(np.abs(sc - ref["Sc"]) / ref["Sc"]) < 2e-5        # per value
+    d = np.abs(stego.astype(int) - ref["stego"].astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+    assert np.abs(yw - ref["Yw"]).max() < 2e-2
+    s = gpu_ctx.ref_sigma(stego)
+    so = np.linalg.svd(stego.astype(np.float64), compute_uv=False)
+    assert np.max(np.abs(s - so) / so) < 2e-5
