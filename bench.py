@@ -89,6 +89,9 @@ def main_fullframe(a):
     """Secondary workload: reference semantics (tile=None) on BASELINE config 2's shape,
     F planes batched through the host-pointer C ABI (PCIe copies of the planes included:
     16.6 MB per 1080p embed+extract against tens of ms of SVD)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("bench.py --mode fullframe is a single-GPU secondary workload (frames shard exactly like "
+                         "the tile mode's; the contract line is the default --mode tile)")
     api = importlib.import_module(PKG + ".hostapi")
     from oracle import wm_oracle as o
     H = a.height if a.height != 2160 else 1080
