@@ -66,6 +66,40 @@ def test_embed_tile_math_vs_oracle(hh, variant, H, W):
     assert np.abs(yw - ref["Yw"]).max() < 3e-2
 
 
+def test_packed_embed_property_random_parameters(hh):
+    """Hypothesis sweep over what the fixed cases do not vary: alpha, the band K, plane size and
+    content (iid noise / smooth field + sensor noise).  Packed production math vs the oracle."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(nby=st.integers(1, 6), nbx=st.integers(1, 8), alpha=st.floats(0.0, 0.3), K=st.integers(0, 8),
+           smooth=st.booleans(), seed=st.integers(0, 2 ** 31 - 1))
+    def prop(nby, nbx, alpha, K, smooth, seed):
+        H, W = 8 * nby, 8 * nbx
+        rng = np.random.default_rng(seed)
+        if smooth:
+            yy, xx = np.mgrid[0:H, 0:W]
+            host = np.clip(120 + 60 * np.sin(xx / 9.0 + seed % 7) * np.cos(yy / 7.0) + rng.normal(0, 1.5, (H, W)), 0, 255).astype(np.uint8)
+        else:
+            host = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+        ref = o.embed_plane(host.astype(np.float32), wys, alpha, kfrac=0.0, tile=8, k_floor=K)
+        nb = nby * nbx
+        sw = np.ascontiguousarray(ref["Sw"].reshape(nb, 8))
+        stego = np.empty((H, W), np.uint8); sc = np.empty((nb, 8), np.float32); yw = np.empty((H, W), np.float32)
+        ms = C.c_int(0); nf = C.c_int(0)
+        hh.hh_embed_tiles_u8_pk(vp(host), vp(sw), vp(stego), vp(sc), vp(yw), H, W, W, C.c_float(alpha), K,
+                                C.byref(ms), C.byref(nf))
+        assert 0 < ms.value <= 9
+        assert _rel(sc, ref["Sc"]) < SIGMA_RTOL
+        ok = np.kron(ref["Sc"][..., 7] > 1e-5 * ref["Sc"][..., 0], np.ones((8, 8), bool))   # tiles with defined vectors
+        d = np.abs(stego.astype(int) - ref["stego"].astype(int))
+        assert d[ok].max(initial=0) <= 1
+        assert np.abs(yw - ref["Yw"])[ok].max(initial=0.0) < 5e-2
+
+    prop()
+
+
 def test_sigma_svd_extract_tile_math_vs_oracle(hh):
     H, W, alpha = 128, 160, 0.15
     host, wys = _inputs(H, W)
