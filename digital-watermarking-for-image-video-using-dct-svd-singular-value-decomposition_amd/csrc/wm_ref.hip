@@ -324,75 +324,61 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 // ---------------------------------------------------------------------------
 // Aug rows of the pair <- R^T x rows, one 64-column tile per workgroup.
 // ---------------------------------------------------------------------------
+// MFMA form (v_mfma_f32_32x32x2_f32; operand layout checked by tools/mfma_probe.hip):
+//   out[i][c] = sum_k R[k][i] X[k][c],  i, k in 0..63 (the pair's rows), c = a 32-column block.
+// A wave owns 32 columns: it loads the 64 x 32 block of X straight from global memory into the B
+// operands (lane j + 32 h holds X[2m + h][c0 + j] for m = 0..31: two coalesced 128-byte rows per
+// load), takes the A operands R[2m + h][i0 + j] from the LDS copy of R, and accumulates both row
+// halves (i0 = 0, 32) in 2 x 16 accumulator registers: 64 MFMAs per block, no LDS traffic for X,
+// in place (the block is fully in registers before the first store).
+typedef float v16f __attribute__((ext_vector_type(16)));
+
 __global__ __launch_bounds__(256) void k_rf_apply(float* __restrict__ aug, const size_t aug_plane_stride,
-                                                 const int ld, const int ncols, const int tiles_per_wg,
+                                                 const int ld, const int ncols, const int blocks_per_wave,
                                                  const int2* __restrict__ pairs, const float* __restrict__ Rall) {
-  __shared__ __attribute__((aligned(16))) float Rs[RP][68];      // [k][i]
-  __shared__ __attribute__((aligned(16))) float Xs[2][RP][68];   // [buffer][k][c]
-  const int t = threadIdx.x, tc = t & 15, ti = t >> 4;
+  __shared__ float Rs[RP][RP + 1];      // [k][i]
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, j = lane & 31, h = lane >> 5;
   const int p = blockIdx.x;
   aug += (size_t)blockIdx.z * aug_plane_stride;
-  Rall += (size_t)blockIdx.z * gridDim.x * RP * RP;
+  const float* Rp = Rall + ((size_t)blockIdx.z * gridDim.x + p) * RP * RP;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = t + 256 * i;
+    Rs[e >> 6][e & 63] = Rp[e];
+  }
+  __syncthreads();
   const int2 pr = pairs[p];
-  const float* Rp = Rall + (size_t)p * RP * RP;
-  // thread t moves float4 number t + 256 i of a 64 x 64 tile: row k = (t >> 4) + 16 i, columns 4 (t & 15)
-  const int kq = t >> 4, c4 = (t & 15) * 4;
-  size_t rowoff[4];
+  const size_t row_x = (size_t)(pr.x * RB + h) * ld, row_y = (size_t)(pr.y * RB + h) * ld;
+  const int blk0 = (blockIdx.y * 4 + wv) * blocks_per_wave;
+  for (int bk = 0; bk < blocks_per_wave; ++bk) {
+    const int c0 = (blk0 + bk) * 32;
+    if (c0 >= ncols) break;                        // wave-uniform
+    const int col = c0 + j;
+    const bool valid = col < ncols;
+    const int colc = valid ? col : ncols - 1;      // loads stay unconditional (a clamped column): per-element
+    const float* px = aug + row_x + colc;          // selects turn into branches that serialise the 32 loads
+    const float* py = aug + row_y + colc;
+    float x[32];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = kq + 16 * i;
-    rowoff[i] = (size_t)((k < RB) ? pr.x * RB + k : pr.y * RB + (k - RB)) * ld;
-    *reinterpret_cast<float4*>(&Rs[k][c4]) = *reinterpret_cast<const float4*>(Rp + k * RP + c4);
-  }
-  auto fetch = [&](size_t ro, int c) -> float4 {
-    if (c + 3 < ncols) return *reinterpret_cast<const float4*>(aug + ro + c);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < ncols) v.x = aug[ro + c];
-    if (c + 1 < ncols) v.y = aug[ro + c + 1];
-    if (c + 2 < ncols) v.z = aug[ro + c + 2];
-    return v;
-  };
-  const int tile0 = blockIdx.y * tiles_per_wg;
-  const int tile_end = min(tile0 + tiles_per_wg, (ncols + 63) / 64);
-  float4 nx[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) nx[i] = fetch(rowoff[i], tile0 * 64 + c4);
-  // output rows of this thread: k = ti * 4 + i
-  size_t outoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = ti * 4 + i;
-    outoff[i] = (size_t)((k < RB) ? pr.x * RB + k : pr.y * RB + (k - RB)) * ld;
-  }
-  int buf = 0;
-  for (int tile = tile0; tile < tile_end; ++tile, buf ^= 1) {
-    float (*X)[68] = Xs[buf];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&X[kq + 16 * i][c4]) = nx[i];
-    if (tile + 1 < tile_end) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) nx[i] = fetch(rowoff[i], (tile + 1) * 64 + c4);
+    for (int m = 0; m < 16; ++m) {
+      x[m] = px[(size_t)(2 * m) * ld];
+      x[16 + m] = py[(size_t)(2 * m) * ld];
     }
-    __syncthreads();           // also orders the R tile; double-buffered X: one barrier per tile
-    float acc[4][4] = {};
-#pragma unroll 8
-    for (int k = 0; k < RP; ++k) {
-      const float4 r = *reinterpret_cast<const float4*>(&Rs[k][ti * 4]);
-      const float4 x = *reinterpret_cast<const float4*>(&X[k][tc * 4]);
-      const float rv[4] = {r.x, r.y, r.z, r.w}, xv[4] = {x.x, x.y, x.z, x.w};
+    v16f acc0 = {0}, acc1 = {0};
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(rv[i], xv[j], acc[i][j]);
+    for (int m = 0; m < 32; ++m) {
+      const float a0 = Rs[2 * m + h][j], a1 = Rs[2 * m + h][32 + j];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x[m], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x[m], acc1, 0, 0, 0);
     }
-    const int gc = tile * 64 + tc * 4;
+    if (valid) {
+      float* ox = aug + (size_t)(pr.x * RB) * ld + col;
+      float* oy = aug + (size_t)(pr.y * RB) * ld + col;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float* o = aug + outoff[i] + gc;
-      if (gc + 3 < ncols) *reinterpret_cast<float4*>(o) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-      else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (gc + j < ncols) o[j] = acc[i][j];
+      for (int v = 0; v < 16; ++v) {
+        const int i = 8 * (v / 4) + 4 * h + (v % 4);     // accumulator register v, lane half h -> output row
+        ox[(size_t)i * ld] = acc0[v];
+        oy[(size_t)i * ld] = acc1[v];
       }
     }
   }
@@ -484,7 +470,7 @@ __global__ void k_rf_gather_rows(const float* __restrict__ src, const int ld, co
 // ---------------------------------------------------------------------------
 struct RefPlan {
   int H, W, L, M, Lp, ld, nbk, npairs, nsteps, nch, B;
-  int apply_tiles;       // 64-column tiles per apply workgroup
+  int apply_tiles;       // 32-column blocks per wave of an apply workgroup (4 waves)
   size_t aug_ps;         // floats between the Aug matrices of consecutive planes
   bool transpose;        // A = plane^T (portrait planes: the short side must index rows)
 };
@@ -502,7 +488,7 @@ RefPlan make_plan(int H, int W, int B = 1) {
   // so a workgroup takes more columns (R / partial-sum traffic amortised, loads pipelined); a single
   // plane keeps the small units that fill the chip.
   const int units = p.npairs * B;                       // (pair, plane) items per step
-  p.apply_tiles = units >= 128 ? 4 : units >= 48 ? 2 : 1;
+  p.apply_tiles = units >= 96 ? 2 : 1;
   p.nch = (p.M + GRAM_CC - 1) / GRAM_CC;    // Gram stays in many small units: a float4 / double-buffered / 512-column variant measured slower (36-40 vs 31 us)
   return p;
 }
@@ -646,8 +632,8 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
                          w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1);
-      const int n_tiles = (ncols + 63) / 64;
-      hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_tiles + p.apply_tiles - 1) / p.apply_tiles, nz), dim3(256), 0, st,
+      const int n_blk = (ncols + 31) / 32, per_wg = 4 * p.apply_tiles;     // 32-column blocks, 4 waves per workgroup
+      hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_blk + per_wg - 1) / per_wg, nz), dim3(256), 0, st,
                          aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R);
     }
   };
