@@ -331,7 +331,7 @@ __global__ void k_copy_border(const uint8_t* host, uint8_t* stego,
 // K2  sigma only
 // ---------------------------------------------------------------------------
 template <bool ALIGNED>
-__global__ __launch_bounds__(WAVE, 4) void k_sigma_tiles(const uint8_t* __restrict__ planes,
+__global__ __launch_bounds__(WAVE, 3) void k_sigma_tiles(const uint8_t* __restrict__ planes,
                                                      float* __restrict__ sigma, const Geom g,
                                                      int* __restrict__ status) {
   int t, ty, tx;
@@ -460,7 +460,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(WAVE, 4) void k_detect_tiles(
+__global__ __launch_bounds__(WAVE, 3) void k_detect_tiles(
     const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
     const float* __restrict__ sigma_w, double* __restrict__ partials, const Geom g,
     const size_t sw_plane_stride, const float inv_alpha, int* __restrict__ status) {
