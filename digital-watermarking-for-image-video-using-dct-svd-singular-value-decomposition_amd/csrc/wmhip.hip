@@ -414,6 +414,18 @@ __global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
   for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
 }
 
+// out[i] = sum over planes z (ascending, deterministic) of in[z][i]: the frames of a clip carry the
+// same watermark, their estimates are averaged (video extract) - on the device, so that one plane
+// instead of n crosses PCIe
+__global__ __launch_bounds__(256) void k_sum_planes(const float* __restrict__ in, const size_t plane_elems, const int n,
+                                                   float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane_elems; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.0f;
+    for (int z = 0; z < n; ++z) acc += in[(size_t)z * plane_elems + i];
+    out[i] = acc;
+  }
+}
+
 // per-watermark preparation for the PX extract: Ux = D^T Uw, Vxt = Vwt D (in place allowed)
 __global__ __launch_bounds__(WAVE) void k_factors_to_pixel(const float* Uw, const float* Vwt, float* Ux, float* Vxt,
                                                           const size_t n_tiles) {
@@ -993,9 +1005,9 @@ int wm_svd_tiles_f32(wm_ctx* ctx, const float* planes, float* U, float* S, float
   return wm_check_status(ctx);
 }
 
-int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
-                        const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
-                        size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+static int extract_tiles_host(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                              const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                              size_t plane_stride, size_t uv_plane_stride, float alpha, int K, bool sum_planes) {
   WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
   if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
   if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
@@ -1004,15 +1016,16 @@ int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
   const size_t span = plane_span(n_planes, H, row_stride, plane_stride, W);
   const size_t n_sc = (size_t)n_planes * nt * 8;
   const size_t n_uv = (uv_plane_stride ? (size_t)n_planes : (size_t)1) * nt * 64;
-  const size_t n_out = (size_t)n_planes * H * W;
+  const size_t hw = (size_t)H * W, n_out = (size_t)n_planes * hw;
   WM_TRY(grow(ctx, &ctx->scratch, &ctx->scratch_bytes,
-              pad256(span) + pad256(n_sc * 4) + 2 * pad256(n_uv * 4) + pad256(n_out * 4) + 2048, "scratch"));
+              pad256(span) + pad256(n_sc * 4) + 2 * pad256(n_uv * 4) + pad256(n_out * 4) + pad256(hw * 4) + 2048, "scratch"));
   Carve cv{(char*)ctx->scratch, 0};
   uint8_t* d_p = cv.take<uint8_t>(span);
   float* d_sc = cv.take<float>(n_sc);
   float* d_U = cv.take<float>(n_uv);
   float* d_V = cv.take<float>(n_uv);
   float* d_o = cv.take<float>(n_out);
+  float* d_sum = cv.take<float>(hw);
   WM_HIP(hipMemcpyAsync(d_p, stego, span, hipMemcpyHostToDevice, ctx->stream));
   if (nt) {
     WM_HIP(hipMemcpyAsync(d_sc, sigma_c, n_sc * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1021,8 +1034,29 @@ int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
   }
   WM_TRY(wm_extract_tiles_u8_dev(ctx, d_p, d_sc, d_U, d_V, d_o, n_planes, H, W, row_stride, plane_stride,
                                  uv_plane_stride, alpha, K));
-  WM_HIP(hipMemcpyAsync(out, d_o, n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (sum_planes) {
+    const size_t g = (hw + 255) / 256;
+    hipLaunchKernelGGL(k_sum_planes, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, d_o, hw, n_planes, d_sum);
+    WM_HIP(hipGetLastError());
+    WM_HIP(hipMemcpyAsync(out, d_sum, hw * 4, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    WM_HIP(hipMemcpyAsync(out, d_o, n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   return wm_check_status(ctx);
+}
+
+int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                        const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                        size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+  return extract_tiles_host(ctx, stego, sigma_c, Uw, Vwt, out, n_planes, H, W, row_stride, plane_stride,
+                            uv_plane_stride, alpha, K, false);
+}
+
+int wm_extract_tiles_sum_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                            const float* Vwt, float* out_sum, int n_planes, int H, int W, int row_stride,
+                            size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
+  return extract_tiles_host(ctx, stego, sigma_c, Uw, Vwt, out_sum, n_planes, H, W, row_stride, plane_stride,
+                            uv_plane_stride, alpha, K, true);
 }
 
 int wm_reconstruct_tiles(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,

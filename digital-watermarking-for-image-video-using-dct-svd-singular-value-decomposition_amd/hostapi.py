@@ -66,6 +66,7 @@ SIGNATURES = {
     "wm_extract_tiles_px_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_tile_factors_to_pixel_dev": [_vp, _vp, _vp, _vp, _vp, _sz],
     "wm_extract_tiles_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_extract_tiles_sum_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_reconstruct_tiles_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "wm_reconstruct_tiles": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "wm_detect_tiles_u8_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f],
@@ -316,7 +317,9 @@ class Context:
         return U, S, Vt
 
     def extract_tiles(self, stego: np.ndarray, sigma_c: np.ndarray, Uw: np.ndarray, Vwt: np.ndarray,
-                      alpha: float, K: int = 8) -> np.ndarray:
+                      alpha: float, K: int = 8, sum_planes: bool = False) -> np.ndarray:
+        """Scrambled-watermark estimate per plane, float32 [n, H, W]; with ``sum_planes`` the planes
+        are added on the device and only their sum [H, W] comes back (video extract averages frames)."""
         if stego.dtype != np.uint8:
             raise ValueError("stego planes must be uint8")
         n, H, W, rs, ps = _plane_layout(stego)
@@ -327,6 +330,12 @@ class Context:
         per_plane = Uw.ndim == 5
         if Uw.shape[-4:] != (nby, nbx, 8, 8) or Vwt.shape != Uw.shape:
             raise ValueError("Uw/Vwt shape mismatch")
+        if sum_planes:
+            tot = np.empty((H, W), np.float32)
+            self._call("wm_extract_tiles_sum_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
+                       _vp(Vwt.ctypes.data), _vp(tot.ctypes.data), n, H, W, rs, ps,
+                       nby * nbx if per_plane else 0, float(alpha), int(K))
+            return tot
         out = np.empty((n, H, W), np.float32)
         self._call("wm_extract_tiles_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
                    _vp(Vwt.ctypes.data), _vp(out.ctypes.data), n, H, W, rs, ps,

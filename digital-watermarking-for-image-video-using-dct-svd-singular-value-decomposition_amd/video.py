@@ -135,11 +135,11 @@ def extract_frames_mean(ctx: hostapi.Context, frames_y: np.ndarray, Sc: np.ndarr
     n, H, W = frames_y.shape
     acc = np.zeros((H, W), np.float64)
     for b0 in range(0, n, batch):
-        if tile:
-            w = ctx.extract_tiles(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Uw, Vwt, alpha, K)
+        if tile:      # the batch's estimates are added on the device: one plane per batch crosses PCIe
+            acc += ctx.extract_tiles(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Uw, Vwt, alpha, K, sum_planes=True)
         else:
             w = ctx.ref_extract_planes(frames_y[b0:b0 + batch], Sc[b0:b0 + batch], Uw, Vwt, alpha, K)
-        acc += w.sum(axis=0, dtype=np.float64)
+            acc += w.sum(axis=0, dtype=np.float64)
     return (acc / max(n, 1)).astype(np.float32)
 
 

@@ -144,6 +144,13 @@ int wm_extract_tiles_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c,
                         int n_planes, int H, int W, int row_stride, size_t plane_stride,
                         size_t uv_plane_stride, float alpha, int K);
 
+/* The same, returning the SUM over the n_planes estimates ([H][W] float32, planes added in
+ * ascending order on the device): the frames of a clip carry one watermark and are averaged by
+ * the video extract, so one plane instead of n_planes crosses PCIe. */
+int wm_extract_tiles_sum_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                            const float* Vwt, float* out_sum, int n_planes, int H, int W, int row_stride,
+                            size_t plane_stride, size_t uv_plane_stride, float alpha, int K);
+
 /* ---- K4: Uw diag(sw_hat) Vwt + idct2 per tile (single:214-218) ----------- */
 int wm_reconstruct_tiles_dev(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt,
                              float* out, int n_planes, int H, int W);

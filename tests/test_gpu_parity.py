@@ -351,3 +351,17 @@ def test_embed_parity_on_smooth_content(gpu_ctx, noise):
     assert d[mask].max() <= 1
     assert (d[mask] != 0).mean() < 2e-3
     assert np.abs(yw - ref["Yw"])[mask].max() < 0.05
+
+
+def test_extract_sum_over_planes(gpu_ctx):
+    """wm_extract_tiles_sum_u8: frames of a clip are added on the device (ascending order)."""
+    H, W, alpha = 64, 96, 0.15
+    host, wys = _inputs(H, W)
+    frames = np.stack([host, host[::-1].copy(), np.random.default_rng(4).integers(0, 256, (H, W), dtype=np.uint8)])
+    U, S, Vt = gpu_ctx.svd_tiles(wys)
+    st, sc, _ = gpu_ctx.embed_tiles(frames, S, alpha)
+    each = gpu_ctx.extract_tiles(st, sc, U, Vt, alpha)
+    tot = gpu_ctx.extract_tiles(st, sc, U, Vt, alpha, sum_planes=True)
+    want = (each[0] + each[1]) + each[2]                  # same order, same float32 additions
+    assert tot.shape == (H, W) and np.array_equal(tot, want)
+    assert np.array_equal(gpu_ctx.extract_tiles(st[:1], sc[:1], U, Vt, alpha, sum_planes=True), each[0])
