@@ -145,76 +145,136 @@ __global__ __launch_bounds__(256) void k_sqdiff_u8(const uint8_t* __restrict__ a
 
 // ---- SSIM (single:44-57): 5 Gaussian-blurred moments per pixel ----------------------
 // 32x32 output tile per 256-thread workgroup, 42x42 halo tile in LDS, separable 11 taps.
-constexpr int ST = 32, SH = 5, SW_ = ST + 2 * SH;   // 42
+// tile of 64 x 32 outputs per workgroup, 5-pixel halo: 74 x 42 inputs (1.52x read amplification)
+constexpr int SH = 5, TX = 64, TY = 32, SWX = TX + 2 * SH, SWY = TY + 2 * SH;
+constexpr int SPX = SWX + 3;                      // LDS pitch of the input tiles: 77 = 13 mod 32, so the 4 rows x 16 stride-4 strips a wave reads land on distinct banks
+constexpr size_t SSIM_LDS_BYTES = (size_t)(2 * SWY * SPX + 5 * SWY * (TX + 1)) * sizeof(float);   // 80,136 B
 
 __device__ __forceinline__ int reflect101(int i, const int n) {
   if (n == 1) return 0;
-  while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
-  return i;
+  const int period = 2 * (n - 1);
+  i %= period; if (i < 0) i += period;
+  return i < n ? i : period - i;
 }
 
 struct GaussTaps { float w[11]; };
 
+// Mean SSIM partial sums: the five 11-tap separable blurs (x, y, xx, yy, xy) fused in LDS.
+//   load 74 x 42 inputs -> horizontal pass (42 rows x 16 strips of 4 outputs) -> vertical pass
+//   (64 columns x 4 strips of 8 rows: every thread busy) + SSIM map -> one double per workgroup.
 template <typename TA, typename TB>
 __global__ __launch_bounds__(256) void k_ssim(const TA* __restrict__ img1, const size_t s1,
                                              const TB* __restrict__ img2, const size_t s2, const int H,
                                              const int W, const GaussTaps taps, double* __restrict__ out) {
-  __shared__ float A[SW_][SW_ + 1], B[SW_][SW_ + 1];
-  __shared__ float Hm[5][SW_][ST + 1];      // horizontally blurred: x, y, xx, yy, xy
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float (*A)[SPX] = reinterpret_cast<float (*)[SPX]>(lds);
+  float (*B)[SPX] = reinterpret_cast<float (*)[SPX]>(lds + SWY * SPX);
+  float (*Hm)[SWY][TX + 1] = reinterpret_cast<float (*)[SWY][TX + 1]>(lds + 2 * SWY * SPX);   // [5][SWY][TX+1]
   __shared__ double red[4];
   const int t = threadIdx.x;
-  const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-  for (int e = t; e < SW_ * SW_; e += 256) {
-    const int ly = e / SW_, lx = e % SW_;
-    const int gy = reflect101(y0 + ly - SH, H), gx = reflect101(x0 + lx - SH, W);
-    A[ly][lx] = (float)img1[(size_t)gy * s1 + gx];
-    B[ly][lx] = (float)img2[(size_t)gy * s2 + gx];
-  }
-  __syncthreads();
-  // horizontal pass: 42 rows x 4 strips of 8 outputs; one strip per work item, 18 loads per operand
-  for (int e = t; e < SW_ * (ST / 8); e += 256) {
-    const int ly = e / (ST / 8), lx0 = (e % (ST / 8)) * 8;
-    float av[18], bv[18];
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  {
+    // one input column per lane, rows ly = (t >> 7) + 2 i.  All 21 + 21 loads are issued before the
+    // first LDS store (a load-store loop serialises on memory latency: 100 -> see DESIGN 7.1).
+    // Borders: one reflection suffices unless the image is smaller than the halo (general formula).
+    const int lx = t & 127;
+    if (lx < SWX) {
+      const bool tiny = (H < 2 * SH + 2) || (W < 2 * SH + 2);
+      auto refl = [&](int i, const int n) -> int {
+        if (tiny) return reflect101(i, n);
+        i = i < 0 ? -i : i;
+        return i >= n ? 2 * n - 2 - i : i;
+      };
+      // columns / rows past the image (tile overhang beyond W or H) may need a second fold; clamp the
+      // source index into range first: those outputs are masked out of the sum anyway
+      const int gx = refl(min(x0 + lx - SH, W + SH - 1), W);
+      const TA* p1 = img1 + gx;
+      const TB* p2 = img2 + gx;
+      float va[SWY / 2], vb[SWY / 2];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) { av[k] = A[ly][lx0 + k]; bv[k] = B[ly][lx0 + k]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
-#pragma unroll
-      for (int k = 0; k < 11; ++k) {
-        const float a = av[j + k], b = bv[j + k], w = taps.w[k];
-        sx = fmaf(w, a, sx); sy = fmaf(w, b, sy);
-        sxx = fmaf(w, a * a, sxx); syy = fmaf(w, b * b, syy); sxy = fmaf(w, a * b, sxy);
+      for (int i = 0; i < SWY / 2; ++i) {
+        const int ly = (t >> 7) + 2 * i;
+        const int gy = refl(min(y0 + ly - SH, H + SH - 1), H);
+        va[i] = (float)p1[(size_t)gy * s1];
+        vb[i] = (float)p2[(size_t)gy * s2];
       }
-      Hm[0][ly][lx0 + j] = sx; Hm[1][ly][lx0 + j] = sy; Hm[2][ly][lx0 + j] = sxx;
-      Hm[3][ly][lx0 + j] = syy; Hm[4][ly][lx0 + j] = sxy;
+#pragma unroll
+      for (int i = 0; i < SWY / 2; ++i) {
+        const int ly = (t >> 7) + 2 * i;
+        A[ly][lx] = va[i];
+        B[ly][lx] = vb[i];
+      }
     }
   }
   __syncthreads();
-  // vertical pass + SSIM map: 32 columns x 4 strips of 8 rows; thread = (column, strip)
+  // horizontal pass: SWY rows x 16 strips of 4 outputs, 14 loads per operand and work item.
+  // The five running sums are kept as two packed pairs (x, y), (xx, yy) and one scalar (xy):
+  // 3 instead of 5 FMAs per tap (the pass is VALU-issue-bound: 113 flop per pixel against 2 bytes).
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  for (int e = t; e < SWY * (TX / 4); e += 256) {
+    const int ly = e >> 4, lx0 = (e & 15) * 4;
+    v2f ab1[14], ab2[14];
+    float ab[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const float a = A[ly][lx0 + k], b = B[ly][lx0 + k];
+      ab1[k] = v2f{a, b};
+      ab2[k] = ab1[k] * ab1[k];
+      ab[k] = a * b;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+      float sxy = 0;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float w = taps.w[k];
+        const v2f wv = {w, w};
+        s1 = __builtin_elementwise_fma(wv, ab1[j + k], s1);
+        s2 = __builtin_elementwise_fma(wv, ab2[j + k], s2);
+        sxy = fmaf(w, ab[j + k], sxy);
+      }
+      Hm[0][ly][lx0 + j] = s1.x; Hm[1][ly][lx0 + j] = s1.y; Hm[2][ly][lx0 + j] = s2.x;
+      Hm[3][ly][lx0 + j] = s2.y; Hm[4][ly][lx0 + j] = sxy;
+    }
+  }
+  __syncthreads();
+  // vertical pass + SSIM map: thread = (column, strip of 8 rows); planes again as (x, y), (xx, yy), xy
   double acc = 0.0;
   const float C1 = (0.01f * 255) * (0.01f * 255), C2 = (0.03f * 255) * (0.03f * 255);
-  if (t < ST * (ST / 8)) {
-    const int lx = t % ST, ly0 = (t / ST) * 8;
-    float m[5][8];
+  {
+    const int lx = t & 63, ly0 = (t >> 6) * 8;
+    v2f m1[8], m2[8];
+    float m5[8];
+    {
+      v2f c1[18], c2[18];
+      float c5[18];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      float col[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k) col[k] = Hm[q][ly0 + k][lx];
+      for (int k = 0; k < 18; ++k) {
+        c1[k] = v2f{Hm[0][ly0 + k][lx], Hm[1][ly0 + k][lx]};
+        c2[k] = v2f{Hm[2][ly0 + k][lx], Hm[3][ly0 + k][lx]};
+        c5[k] = Hm[4][ly0 + k][lx];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float s = 0;
+        v2f a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+        float a5 = 0;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) s = fmaf(taps.w[k], col[j + k], s);
-        m[q][j] = s;
+        for (int k = 0; k < 11; ++k) {
+          const float w = taps.w[k];
+          const v2f wv = {w, w};
+          a1 = __builtin_elementwise_fma(wv, c1[j + k], a1);
+          a2 = __builtin_elementwise_fma(wv, c2[j + k], a2);
+          a5 = fmaf(w, c5[j + k], a5);
+        }
+        m1[j] = a1; m2[j] = a2; m5[j] = a5;
       }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (y0 + ly0 + j >= H || x0 + lx >= W) continue;
-      const float mu1 = m[0][j], mu2 = m[1][j];
-      const float s1q = m[2][j] - mu1 * mu1, s2q = m[3][j] - mu2 * mu2, s12 = m[4][j] - mu1 * mu2;
+      const float mu1 = m1[j].x, mu2 = m1[j].y;
+      const float s1q = m2[j].x - mu1 * mu1, s2q = m2[j].y - mu2 * mu2, s12 = m5[j] - mu1 * mu2;
       const float num = (2 * mu1 * mu2 + C1) * (2 * s12 + C2);
       const float den = (mu1 * mu1 + mu2 * mu2 + C1) * (s1q + s2q + C2) + 1e-12f;
       acc += (double)(num / den);
@@ -380,17 +440,25 @@ int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2,
   if (!ctx || !img1 || !img2 || !ssim_dev) return set_err(WM_ERR_BADARG, "NULL argument");
   WM_TRY(wmi::use_ctx(ctx));
   if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
-  const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST), block(256);
+  const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY), block(256);
   const size_t nblk = (size_t)grid.x * grid.y;
   WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, (nblk + 1) * sizeof(double), "ssim partial sums"));
   double* part = (double*)ctx->partials;
   const GaussTaps taps = make_taps();
+#define WM_LAUNCH_SSIM(TA_, TB_)                                                                              \
+  do { /* 80 KB of dynamic LDS is above the 64 KB default cap: raise it (per device, cheap) */                \
+    WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ssim<TA_, TB_>),                              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_LDS_BYTES));             \
+    hipLaunchKernelGGL((k_ssim<TA_, TB_>), grid, block, SSIM_LDS_BYTES, ctx->stream, (const TA_*)img1,        \
+                       stride1, (const TB_*)img2, stride2, H, W, taps, part);                                 \
+  } while (0)
   switch (kind & 3) {
-    case 0: hipLaunchKernelGGL((k_ssim<uint8_t, uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)img1, stride1, (const uint8_t*)img2, stride2, H, W, taps, part); break;
-    case 1: hipLaunchKernelGGL((k_ssim<float, uint8_t>), grid, block, 0, ctx->stream, (const float*)img1, stride1, (const uint8_t*)img2, stride2, H, W, taps, part); break;
-    case 2: hipLaunchKernelGGL((k_ssim<uint8_t, float>), grid, block, 0, ctx->stream, (const uint8_t*)img1, stride1, (const float*)img2, stride2, H, W, taps, part); break;
-    default: hipLaunchKernelGGL((k_ssim<float, float>), grid, block, 0, ctx->stream, (const float*)img1, stride1, (const float*)img2, stride2, H, W, taps, part); break;
+    case 0: WM_LAUNCH_SSIM(uint8_t, uint8_t); break;
+    case 1: WM_LAUNCH_SSIM(float, uint8_t); break;
+    case 2: WM_LAUNCH_SSIM(uint8_t, float); break;
+    default: WM_LAUNCH_SSIM(float, float); break;
   }
+#undef WM_LAUNCH_SSIM
   hipLaunchKernelGGL(k_sum_f64, dim3(1), dim3(256), 0, ctx->stream, part, nblk, 1.0 / ((double)H * (double)W), ssim_dev);
   WM_HIP(hipGetLastError());
   return WM_OK;
