@@ -102,7 +102,11 @@ def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
         return np.repeat(np.repeat(img, H // h, axis=0), W // w, axis=1)
     My, Mx = _area_matrix(h, H), _area_matrix(w, W)
     src = img.astype(np.float64)
-    out = My @ src @ Mx.T if src.ndim == 2 else np.einsum("dh,hwc,ew->dec", My, src, Mx)
+    if src.ndim == 2:
+        out = My @ src @ Mx.T
+    else:   # every channel is resized like a gray image: two small BLAS products each (a 3-operand
+            # einsum walks H*W*h*w*c terms - 70 s for a 64x64 logo on a 1080p cover)
+        out = np.stack([My @ src[..., c] @ Mx.T for c in range(src.shape[2])], axis=-1)
     return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
 
 

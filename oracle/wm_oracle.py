@@ -386,8 +386,8 @@ def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
     My = axis_weights(h, H); Mx = axis_weights(w, W)
     if src.ndim == 2:
         out = My @ src @ Mx.T
-    else:
-        out = np.einsum("dh,hwc,ew->dec", My, src, Mx)
+    else:                                     # every channel is resized like a gray image
+        out = np.stack([My @ src[..., c] @ Mx.T for c in range(src.shape[2])], axis=-1)
     return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
 
 
