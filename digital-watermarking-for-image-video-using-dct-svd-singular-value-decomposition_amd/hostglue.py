@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import hashlib
 import hmac as _hmac
+import threading
+from collections import OrderedDict
 
 import numpy as np
 import scipy.ndimage
@@ -107,7 +109,10 @@ def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
     else:   # every channel is resized like a gray image: two small BLAS products each (a 3-operand
             # einsum walks H*W*h*w*c terms - 70 s for a 64x64 logo on a 1080p cover)
         out = np.stack([My @ src[..., c] @ Mx.T for c in range(src.shape[2])], axis=-1)
-    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+    out += 0.5                                  # round half up, in place (the planes are tens of MB)
+    np.floor(out, out=out)
+    np.clip(out, 0, 255, out=out)
+    return out.astype(np.uint8)
 
 
 # ---- security wrapper (single:59-86) -----------------------------------------
@@ -119,11 +124,29 @@ def rng_from_key(key: bytes) -> np.random.Generator:
     return np.random.default_rng(int.from_bytes(key[:8], "big", signed=False))
 
 
+_perm_cache: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
+_perm_lock = threading.Lock()
+_PERM_CACHE_ENTRIES = 2
+
+
 def permutation_index(H: int, W: int, key: bytes) -> np.ndarray:
     """``idx = np.arange(H*W); rng.shuffle(idx)`` (single:68-69,124,219,265):
-    bit-exact because it *is* the same NumPy PCG64 call."""
+    bit-exact because it *is* the same NumPy PCG64 call.  The shuffle is sequential host work
+    (0.15 s for a 4K plane), so the last two (H, W, key) results are kept: an extract right after an
+    embed, or the frames of one video, pay for it once.  The returned array is read-only."""
+    k = (int(H), int(W), bytes(key))
+    with _perm_lock:
+        idx = _perm_cache.get(k)
+        if idx is not None:
+            _perm_cache.move_to_end(k)
+            return idx
     idx = np.arange(H * W)
     rng_from_key(key).shuffle(idx)
+    idx.setflags(write=False)
+    with _perm_lock:
+        _perm_cache[k] = idx
+        while len(_perm_cache) > _PERM_CACHE_ENTRIES:
+            _perm_cache.popitem(last=False)
     return idx
 
 

@@ -58,3 +58,23 @@ def test_png_roundtrip_and_errors(tmp_path):
     with pytest.raises(ValueError):
         hg.read_image_bgr(str(tmp_path / "missing.png"))
     assert not hg.write_png(str(tmp_path / "no_such_dir" / "x.png"), a, 0)
+
+
+def test_permutation_index_cache_and_resize_speed():
+    """The keyed shuffle is cached per (H, W, key) (read-only array, same object on a hit, evicted
+    after two other keys); the watermark resize of a small colour logo onto a large cover must stay
+    a BLAS-sized job (it once was a 70 s einsum)."""
+    import time
+    k1, k2, k3 = (o.derive_key(p, bytes(8)) for p in ("a", "b", "c"))
+    i1 = hg.permutation_index(40, 56, k1)
+    assert hg.permutation_index(40, 56, k1) is i1 and not i1.flags.writeable
+    assert np.array_equal(i1, o.permutation(40, 56, o.rng_from_key(k1)))
+    hg.permutation_index(40, 56, k2); hg.permutation_index(40, 56, k3)
+    i1b = hg.permutation_index(40, 56, k1)
+    assert i1b is not i1 and np.array_equal(i1b, i1)                # evicted, recomputed identically
+    assert np.array_equal(hg.permutation_index(56, 40, k1), i1)    # the shuffle only knows H*W
+    wm = np.random.default_rng(0).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    t0 = time.perf_counter()
+    r = hg.resize_area(wm, 1000, 600)
+    assert time.perf_counter() - t0 < 5.0 and r.shape == (600, 1000, 3)
+    assert np.array_equal(r, o.resize_area(wm, 1000, 600))
