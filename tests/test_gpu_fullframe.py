@@ -178,3 +178,29 @@ def test_fullframe_parity_on_smooth_content(gpu_ctx, noise):
     s = gpu_ctx.ref_sigma(stego)
     so = np.linalg.svd(stego.astype(np.float64), compute_uv=False)
     assert np.max(np.abs(s - so) / so) < 2e-5
+
+
+def test_fullframe_batch_of_mixed_content(gpu_ctx):
+    """One batched call over planes that converge at different speeds (noise, flat, letterbox,
+    smooth): the sweeps run until the slowest plane is done; every plane must still match its own
+    single-plane result and float64 LAPACK."""
+    H, W = 96, 160
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:H, 0:W]
+    planes = np.stack([
+        rng.integers(0, 256, (H, W), dtype=np.uint8),
+        np.full((H, W), 200, np.uint8),
+        np.where((yy < 12) | (yy >= H - 12), 16, rng.integers(0, 256, (H, W))).astype(np.uint8),
+        np.clip(128 + 90 * np.sin(xx / 11.0) * np.cos(yy / 7.0) + rng.normal(0, 1, (H, W)), 0, 255).astype(np.uint8),
+        rng.integers(0, 256, (H, W), dtype=np.uint8),
+    ])
+    sig = gpu_ctx.ref_sigma_planes(planes)
+    Sw = np.sort(rng.uniform(10, 3000, H).astype(np.float32))[::-1].copy()
+    st, sc, yw = gpu_ctx.ref_embed_planes(planes, Sw, 0.15, 57, want_yw=True)
+    for z in range(len(planes)):
+        ref = np.linalg.svd(planes[z].astype(np.float64), compute_uv=False)
+        assert np.abs(sig[z] - ref).max() < 2e-6 * ref[0], z
+        assert np.abs(sc[z] - ref).max() < 2e-6 * ref[0], z
+        s1, c1, y1 = gpu_ctx.ref_embed(planes[z], Sw, 0.15, 57, want_yw=True)
+        assert np.abs(st[z].astype(int) - s1.astype(int)).max() <= 1, z
+        assert np.abs(yw[z] - y1).max() < 2e-2, z
