@@ -130,3 +130,40 @@ def test_video_fullframe_mode(tmp_path, gpu_ctx):
     marked = np.stack([g[0] for g in got[::2]])
     one = [gpu_ctx.ref_detect(marked[i], data["Sc"][i], data["Sw"], 0.15) for i in range(5)]
     assert np.allclose(gpu_ctx.ref_detect_planes(marked, data["Sc"], data["Sw"], 0.15), one, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_video_parameter_sweep(tmp_path, gpu_ctx):
+    """Frame counts that do not divide the batch, frame_interval > 1, ragged frame sizes, one-frame
+    clips, mono clips, both modes: marked frames are detected, unmarked clips are not, untouched
+    frames and chroma stay bit-identical, the meta counts add up."""
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    rng = np.random.default_rng(31)
+    wm = rng.integers(0, 256, (16, 24, 3), dtype=np.uint8)
+    wp = str(tmp_path / "wm.png"); assert hg.write_png(wp, wm)
+    cases = [dict(n=7, H=64, W=96, fi=1, batch=3, tile=8), dict(n=5, H=52, W=84, fi=2, batch=2, tile=8),
+             dict(n=1, H=64, W=64, fi=1, batch=4, tile=8), dict(n=6, H=48, W=80, fi=3, batch=8, tile=None),
+             dict(n=4, H=96, W=64, fi=1, batch=3, tile=None)]
+    for i, c in enumerate(cases):
+        sub = tmp_path / f"c{i}"; sub.mkdir()
+        v, p, ys, chroma = _video(sub, n=c["n"], H=c["H"], W=c["W"], seed=40 + i)
+        outp, meta, ps = v.embed_watermark_video(p, wp, str(sub / "out.y4m"), str(sub / "m.npz"), alpha=0.15,
+                                                 frame_interval=c["fi"], password="pw", nonce=bytes(8),
+                                                 batch=c["batch"], tile=c["tile"])
+        data = np.load(meta, allow_pickle=False)
+        n_marked = len(range(0, c["n"], c["fi"]))
+        assert data["Sc"].shape[0] == n_marked and int(data["n_frames"]) == c["n"], c
+        vid = v.Y4M(outp); got = [(y.copy(), ch.copy()) for _, y, ch in vid]; vid.close()
+        assert len(got) == c["n"]
+        for k, (y, ch) in enumerate(got):
+            assert np.array_equal(ch, chroma[k])
+            if k % c["fi"]:
+                assert np.array_equal(y, ys[k])
+            else:
+                assert not np.array_equal(y, ys[k])
+        ok, mean, scores = v.detect_watermark_video(outp, meta, batch=c["batch"])
+        assert ok and scores.shape == (n_marked,) and scores.min() > 0.8, (c, scores)
+        ok0, _, _ = v.detect_watermark_video(p, meta, batch=c["batch"])
+        assert not ok0, c
+        w = v.extract_watermark_video(outp, meta, str(sub / "w.png"), password="pw", batch=c["batch"])
+        assert hg.read_image_bgr(w).shape[:2] == (c["H"], c["W"])
