@@ -26,7 +26,11 @@ def read_image_bgr(path: str) -> np.ndarray:
     """``cv2.imread(path, cv2.IMREAD_COLOR)``: always 3-channel BGR uint8."""
     try:
         with Image.open(path) as im:
-            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+            if im.mode in ("I;16", "I;16L", "I;16B", "I"):         # 16-bit gray: OpenCV keeps the high byte
+                g = (np.asarray(im).astype(np.uint32) >> 8).clip(0, 255).astype(np.uint8)
+                rgb = np.repeat(g[..., None], 3, axis=2)
+            else:
+                rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
     except Exception:
         raise ValueError(f"Không mở được ảnh: {path}")          # single:17-18
     return np.ascontiguousarray(rgb[..., ::-1])
