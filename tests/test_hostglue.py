@@ -78,3 +78,25 @@ def test_permutation_index_cache_and_resize_speed():
     r = hg.resize_area(wm, 1000, 600)
     assert time.perf_counter() - t0 < 5.0 and r.shape == (600, 1000, 3)
     assert np.array_equal(r, o.resize_area(wm, 1000, 600))
+
+
+def test_read_image_modes(tmp_path):
+    """cv2.imread(IMREAD_COLOR) semantics for what Pillow hands back: gray, gray+alpha, RGBA, palette,
+    1-bit and 16-bit PNGs all come out as 3-channel 8-bit BGR."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (12, 18, 3), dtype=np.uint8)
+    g = rgb[..., 0]
+    cases = {
+        "L": (Image.fromarray(g), np.repeat(g[..., None], 3, 2)),
+        "RGB": (Image.fromarray(rgb), rgb[..., ::-1]),
+        "RGBA": (Image.fromarray(np.dstack([rgb, g])), rgb[..., ::-1]),
+        "LA": (Image.fromarray(np.dstack([g, rgb[..., 1]]), "LA"), np.repeat(g[..., None], 3, 2)),
+        "I16": (Image.fromarray(g.astype(np.uint16) * 257), np.repeat(g[..., None], 3, 2)),
+        "1": (Image.fromarray(g > 128), np.repeat(((g > 128) * 255).astype(np.uint8)[..., None], 3, 2)),
+    }
+    for name, (im, want) in cases.items():
+        p = str(tmp_path / (name + ".png")); im.save(p)
+        got = hg.read_image_bgr(p)
+        assert got.dtype == np.uint8 and got.shape == (12, 18, 3) and got.flags.c_contiguous, name
+        assert np.array_equal(got, want), name
