@@ -137,43 +137,53 @@ __global__ void k_rf_load(const T* __restrict__ src, const size_t src_stride, co
 // Gram partials: for pair p = (I, J) and column chunk ch,
 //   partial[p][ch][r][c] = sum_{k in chunk} X[r][k] X[c][k],  X = rows of blocks I,J
 // ---------------------------------------------------------------------------
+// MFMA form: the 64 x 128 chunk of X is staged row-major in LDS (pitch 129: the operand reads
+// X[i0 + lane%32][k + lane/32] of a wave hit 32 distinct banks twice), wave w owns the 32 x 32
+// quadrant (w >> 1, w & 1) of the Gram matrix and issues 64 v_mfma_f32_32x32x2_f32 whose A and B
+// operands both come from X (D = X_I X_J^T).
+typedef float v16f_g __attribute__((ext_vector_type(16)));
+constexpr int GP = GRAM_CC + 1;
+
 __global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, const size_t aug_plane_stride,
                                                 const int ld, const int M, const int2* __restrict__ pairs,
                                                 float* __restrict__ partials) {
-  __shared__ __attribute__((aligned(16))) float Xt[32][68];   // [k][row]
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  __shared__ float Xs[RP][GP];
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, j = lane & 31, h = lane >> 5;
   const int p = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
   aug += (size_t)blockIdx.z * aug_plane_stride;
   partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
   const int2 pr = pairs[p];
-  const int c_begin = ch * GRAM_CC, c_end = min(M, c_begin + GRAM_CC);
-  float acc[4][4] = {};
-  for (int c0 = c_begin; c0 < c_end; c0 += 32) {
+  const int c_begin = ch * GRAM_CC;
+  {
+    // 64 rows x 128 columns: thread t takes column t & 127 of rows (t >> 7) + 2 i; all 32 loads are
+    // issued before the LDS stores
+    const int c = t & 127, gc = c_begin + c;
+    const bool valid = gc < M;
+    const int gcc = valid ? gc : M - 1;
+    float v[32];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = t + 256 * i;             // 64 rows x 32 cols
-      const int r = e >> 5, k = e & 31;
+    for (int i = 0; i < 32; ++i) {
+      const int r = (t >> 7) + 2 * i;
       const int grow = (r < RB) ? pr.x * RB + r : pr.y * RB + (r - RB);
-      const int gc = c0 + k;
-      Xt[k][r] = (gc < c_end) ? aug[(size_t)grow * ld + gc] : 0.0f;
+      v[i] = aug[(size_t)grow * ld + gcc];
     }
-    __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-      const float4 a = *reinterpret_cast<const float4*>(&Xt[kk][ty * 4]);
-      const float4 b = *reinterpret_cast<const float4*>(&Xt[kk][tx * 4]);
-      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
-    }
-    __syncthreads();
+    for (int i = 0; i < 32; ++i) Xs[(t >> 7) + 2 * i][c] = valid ? v[i] : 0.0f;
   }
+  __syncthreads();
+  const int i0 = (wv >> 1) * 32, j0 = (wv & 1) * 32;
+  const float* ra = &Xs[i0 + j][h];
+  const float* rb = &Xs[j0 + j][h];
+  v16f_g acc = {0};
+#pragma unroll 16
+  for (int kk = 0; kk < GRAM_CC / 2; ++kk)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk], rb[2 * kk], acc, 0, 0, 0);
   float* out = partials + ((size_t)p * nch + ch) * RP * RP;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    *reinterpret_cast<float4*>(&out[(ty * 4 + i) * RP + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  for (int v = 0; v < 16; ++v) {
+    const int row = i0 + 8 * (v / 4) + 4 * h + (v % 4);
+    out[row * RP + j0 + j] = acc[v];
+  }
 }
 
 // ---------------------------------------------------------------------------
