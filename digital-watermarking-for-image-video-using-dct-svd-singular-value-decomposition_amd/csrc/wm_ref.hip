@@ -44,60 +44,80 @@ constexpr double NULL_ROW_RATIO = 1e-5;   // rows below this fraction of |A|_F d
 constexpr double NULL_RATIO = 1e-6;   // embed: singular directions below this fraction of s_1 get no watermark energy
 
 // ---------------------------------------------------------------------------
-// generic row-major SGEMM:  C = alpha * op(A) op(B) + beta * C
-// 64x64 tile, 256 threads, 4x4 per thread, K step 16.  Plain-library-GEMM
-// shaped work (DCT as two GEMMs, U diag V^T products); not the hot loop.
+// generic row-major SGEMM:  C = alpha * op(A) op(B) + beta * C  on MFMA
+// (v_mfma_f32_32x32x2_f32).  64x64 tile of C per workgroup, one 32x32 quadrant per wave,
+// K step 32 staged through LDS in operand-friendly layouts - As[m][k] pitch 33 (the A operand
+// A[m0 + lane%32][k + lane/32] hits 32 banks), Bs[k][n] pitch 65 - with the next step's global
+// loads issued before this step's 16 MFMAs.  Plain-library-GEMM shaped work of the full-frame
+// mode (DCT as two GEMMs, T = A0 B^T, U diag V^T products).
 // ---------------------------------------------------------------------------
+typedef float v16f_s __attribute__((ext_vector_type(16)));
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_sgemm(const int M, const int N, const int K, const float alpha,
                                               const float* __restrict__ A, const int lda,
                                               const float* __restrict__ B, const int ldb,
                                               const float beta, float* __restrict__ C, const int ldc) {
-  __shared__ __attribute__((aligned(16))) float As[16][68];   // [k][m]
-  __shared__ __attribute__((aligned(16))) float Bs[16][68];   // [k][n]
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  constexpr int KS = 32;
+  __shared__ float As[2][64][KS + 1];   // [m][k]
+  __shared__ float Bs[2][KS][64 + 1];   // [k][n]
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, j = lane & 31, h = lane >> 5;
   const int bm = blockIdx.y * 64, bn = blockIdx.x * 64;
-  float acc[4][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  // staging maps: 2048 elements of each tile, 8 per thread, lanes along the contiguous global axis
+  //   A stored [m][k] (TA = false): e -> m = e >> 5, k = e & 31;   A stored [k][m] (TA): k = e >> 6, m = e & 63
+  //   B stored [k][n] (TB = false): e -> k = e >> 6, n = e & 63;   B stored [n][k] (TB): n = e >> 5, k = e & 31
+  float ra[8], rb[8];
+  auto fetch = [&](const int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int e = t + 256 * i;
-      int m, k;
-      if (TA) { k = e >> 6; m = e & 63; } else { m = e >> 4; k = e & 15; }
-      const int gm = bm + m, gk = k0 + k;
-      float v = 0.0f;
-      if (gm < M && gk < K) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-      As[k][m] = v;
-      int n, kb;
-      if (TB) { n = e >> 4; kb = e & 15; } else { kb = e >> 6; n = e & 63; }
+      const int m = TA ? (e & 63) : (e >> 5), ka = TA ? (e >> 6) : (e & 31);
+      const int gm = bm + m, gk = k0 + ka;
+      const bool oka = gm < M && gk < K;
+      const size_t ia = TA ? (size_t)(oka ? gk : 0) * lda + (oka ? gm : 0) : (size_t)(oka ? gm : 0) * lda + (oka ? gk : 0);
+      const float va = A[ia];
+      ra[i] = oka ? va : 0.0f;
+      const int n = TB ? (e >> 5) : (e & 63), kb = TB ? (e & 31) : (e >> 6);
       const int gn = bn + n, gkb = k0 + kb;
-      float w = 0.0f;
-      if (gn < N && gkb < K) w = TB ? B[(size_t)gn * ldb + gkb] : B[(size_t)gkb * ldb + gn];
-      Bs[kb][n] = w;
+      const bool okb = gn < N && gkb < K;
+      const size_t ib = TB ? (size_t)(okb ? gn : 0) * ldb + (okb ? gkb : 0) : (size_t)(okb ? gkb : 0) * ldb + (okb ? gn : 0);
+      const float vb = B[ib];
+      rb[i] = okb ? vb : 0.0f;
     }
-    __syncthreads();
+  };
+  auto stash = [&](const int buf) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-      const float4 b = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
-      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
+    for (int i = 0; i < 8; ++i) {
+      const int e = t + 256 * i;
+      const int m = TA ? (e & 63) : (e >> 5), ka = TA ? (e >> 6) : (e & 31);
+      As[buf][m][ka] = ra[i];
+      const int n = TB ? (e >> 5) : (e & 63), kb = TB ? (e & 31) : (e >> 6);
+      Bs[buf][kb][n] = rb[i];
     }
-    __syncthreads();
+  };
+  const int m0 = (wv >> 1) * 32, n0 = (wv & 1) * 32;
+  v16f_s acc = {0};
+  fetch(0);
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += KS, buf ^= 1) {
+    stash(buf);
+    if (k0 + KS < K) fetch(k0 + KS);
+    __syncthreads();                    // double-buffered LDS: one barrier per K step
+    const float* pa = &As[buf][m0 + j][h];
+    const float* pb = &Bs[buf][h][n0 + j];
+#pragma unroll
+    for (int kk = 0; kk < KS / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk], pb[2 * kk * 65], acc, 0, 0, 0);
   }
+  const int gn = bn + n0 + j;
+  if (gn < N) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gm = bm + ty * 4 + i;
-    if (gm >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gn = bn + tx * 4 + j;
-      if (gn >= N) continue;
-      float* c = C + (size_t)gm * ldc + gn;
-      *c = (beta == 0.0f) ? alpha * acc[i][j] : __builtin_fmaf(beta, *c, alpha * acc[i][j]);
+    for (int v = 0; v < 16; ++v) {
+      const int gm = bm + m0 + 8 * (v / 4) + 4 * h + (v % 4);
+      if (gm < M) {
+        float* c = C + (size_t)gm * ldc + gn;
+        *c = (beta == 0.0f) ? alpha * acc[v] : __builtin_fmaf(beta, *c, alpha * acc[v]);
+      }
     }
   }
 }
