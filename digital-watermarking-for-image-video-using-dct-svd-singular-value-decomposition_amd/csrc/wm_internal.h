@@ -44,8 +44,9 @@ struct wm_ctx {
   float* dct_mat[2] = {nullptr, nullptr};   // cached DCT-II basis matrices (device), by size
   int dct_n[2] = {0, 0};
   int ref_last_sweeps = 0;        // outer Jacobi sweeps of the last full-frame SVD (diagnostics)
-  hipStream_t aux_stream = nullptr;   // second queue of the batched full-frame Jacobi (created on first use)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int MAX_AUX = 3;   // extra queues of the batched full-frame Jacobi (created on first use)
+  hipStream_t aux_stream[MAX_AUX] = {};
+  hipEvent_t ev_fork[MAX_AUX] = {}, ev_join[MAX_AUX] = {};
   hipEvent_t ev[wmi::N_EVENTS] = {};
 };
 

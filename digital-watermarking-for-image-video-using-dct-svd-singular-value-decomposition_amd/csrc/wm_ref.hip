@@ -39,6 +39,7 @@ constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to 
 // sigma-only calls (extract, detect): row norms are exact to O(cos^2), and the sweep that
 // observes max cos < c still rotates (leaving ~c^2), so they may stop an order earlier (2e-3 already costs 7e-5 relative on dense spectra: tools/ff_sigma_thr.py)
 constexpr float CONV_COS_SIGMA = 2e-4f;
+constexpr int DEFAULT_QUEUES = 2;         // plane groups of a batched Jacobi, each on its own HIP queue
 constexpr double DRIFT_TOL = 1e-2;        // |T[:, i]| / |b_i|^2 may differ from 1 by the scale drift, not more
 constexpr double NULL_ROW_RATIO = 1e-5;   // rows below this fraction of |A|_F do not take part in the convergence test
 constexpr double NULL_RATIO = 1e-6;   // embed: singular directions below this fraction of s_1 get no watermark energy
@@ -627,15 +628,23 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
   bool done = false;
   std::vector<unsigned> bits(p.B);
   static const int full_sweeps = getenv("WM_RF_FULL_SWEEPS") ? atoi(getenv("WM_RF_FULL_SWEEPS")) : FULL_INNER_SWEEPS;
-  static const bool two_queues = !(getenv("WM_RF_ONE_QUEUE") && atoi(getenv("WM_RF_ONE_QUEUE")));
+  // number of plane groups (HIP queues): WM_RF_QUEUES=n (1..4), WM_RF_ONE_QUEUE=1 is the old spelling of n = 1
+  static const int max_queues = [] {
+    if (getenv("WM_RF_ONE_QUEUE") && atoi(getenv("WM_RF_ONE_QUEUE"))) return 1;
+    const int n = getenv("WM_RF_QUEUES") ? atoi(getenv("WM_RF_QUEUES")) : DEFAULT_QUEUES;
+    return n < 1 ? 1 : (n > 1 + wm_ctx::MAX_AUX ? 1 + wm_ctx::MAX_AUX : n);
+  }();
   static const float conv_sigma = getenv("WM_RF_CONV_SIGMA") ? (float)atof(getenv("WM_RF_CONV_SIGMA")) : CONV_COS_SIGMA;
   const float conv_cos = with_q ? CONV_COS : conv_sigma;
-  const int B0 = (p.B >= 2 && two_queues) ? (p.B + 1) / 2 : p.B, B1 = p.B - B0;
-  if (B1 > 0 && !ctx->aux_stream) {
-    WM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    WM_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    WM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-  }
+  const int NQ = std::min(max_queues, p.B);               // group g owns planes [zb[g], zb[g + 1])
+  int zb[2 + wm_ctx::MAX_AUX];
+  for (int g = 0; g <= NQ; ++g) zb[g] = (int)((long long)g * p.B / NQ);
+  for (int g = 1; g < NQ; ++g)
+    if (!ctx->aux_stream[g - 1]) {
+      WM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream[g - 1], hipStreamNonBlocking));
+      WM_HIP(hipEventCreateWithFlags(&ctx->ev_fork[g - 1], hipEventDisableTiming));
+      WM_HIP(hipEventCreateWithFlags(&ctx->ev_join[g - 1], hipEventDisableTiming));
+    }
   // numerical-null floor per plane: (NULL_ROW_RATIO * |A|_F)^2 from the row norms of the loaded input
   {
     hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, 0, w.b2, w.q2);
@@ -669,20 +678,20 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
   };
   while (!done && sweep < MAX_SWEEPS) {
     WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));
-    if (B1 > 0) {
-      step(ctx->stream, 0, B0, 0, 1);                          // group 0's first gram, then fork
-      WM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-      WM_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-      step(ctx->stream, 0, B0, 0, 2);
-      step(ctx->aux_stream, B0, B1, 0, 3);
-      for (int s = 1; s < p.nsteps; ++s) {
-        step(ctx->stream, 0, B0, s, 3);
-        step(ctx->aux_stream, B0, B1, s, 3);
-      }
-      WM_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-      WM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    } else {
-      for (int s = 0; s < p.nsteps; ++s) step(ctx->stream, 0, B0, s, 3);
+    // group g starts one gram after group g - 1, so that the groups' latency-bound inner solves
+    // fall under each other's gram / apply tiles instead of all at the same time
+    auto q = [&](int g) { return g == 0 ? ctx->stream : ctx->aux_stream[g - 1]; };
+    for (int g = 0; g < NQ; ++g) {
+      if (g > 0) WM_HIP(hipStreamWaitEvent(q(g), ctx->ev_fork[g - 1], 0));
+      step(q(g), zb[g], zb[g + 1] - zb[g], 0, 1);
+      if (g + 1 < NQ) WM_HIP(hipEventRecord(ctx->ev_fork[g], q(g)));
+    }
+    for (int g = 0; g < NQ; ++g) step(q(g), zb[g], zb[g + 1] - zb[g], 0, 2);
+    for (int s = 1; s < p.nsteps; ++s)
+      for (int g = 0; g < NQ; ++g) step(q(g), zb[g], zb[g + 1] - zb[g], s, 3);
+    for (int g = 1; g < NQ; ++g) {
+      WM_HIP(hipEventRecord(ctx->ev_join[g - 1], q(g)));
+      WM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g - 1], 0));
     }
     WM_HIP(hipGetLastError());
     WM_HIP(hipMemcpyAsync(bits.data(), w.maxcos, (size_t)p.B * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));

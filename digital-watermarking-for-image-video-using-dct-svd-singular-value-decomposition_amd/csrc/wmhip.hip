@@ -642,9 +642,11 @@ int wm_destroy(wm_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < N_EVENTS; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (int i = 0; i < wm_ctx::MAX_AUX; ++i) {
+    if (ctx->aux_stream[i]) { (void)hipStreamSynchronize(ctx->aux_stream[i]); (void)hipStreamDestroy(ctx->aux_stream[i]); }
+    if (ctx->ev_fork[i]) (void)hipEventDestroy(ctx->ev_fork[i]);
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->partials) (void)hipFree(ctx->partials);
