@@ -39,6 +39,7 @@ constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to 
 // sigma-only calls (extract, detect): row norms are exact to O(cos^2), and the sweep that
 // observes max cos < c still rotates (leaving ~c^2), so they may stop an order earlier (2e-3 already costs 7e-5 relative on dense spectra: tools/ff_sigma_thr.py)
 constexpr float CONV_COS_SIGMA = 2e-4f;
+constexpr float SKIP_FRACTION = 0.25f;    // a block pair below this fraction of the stopping cosine is left alone
 constexpr int DEFAULT_QUEUES = 2;         // plane groups of a batched Jacobi, each on its own HIP queue
 constexpr double DRIFT_TOL = 1e-2;        // |T[:, i]| / |b_i|^2 may differ from 1 by the scale drift, not more
 constexpr double NULL_ROW_RATIO = 1e-5;   // rows below this fraction of |A|_F do not take part in the convergence test
@@ -231,7 +232,8 @@ constexpr int INNER_NW = INNER_NT / 64;
 
 __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__ partials, const int nch,
                                                       float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits,
-                                                      const float* __restrict__ floor2, const int cross_only) {
+                                                      const float* __restrict__ floor2, const int cross_only,
+                                                      int* __restrict__ skip_flags, const float skip_thr) {
   __shared__ float GG[2][RP][RP + 1];   // double-buffered: a step reads one copy, writes the other
   float (*G)[RP + 1] = GG[0];
   __shared__ float R[RP][RP + 1];
@@ -287,12 +289,20 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
   if ((t & 63) == 0) red[t >> 6] = mx;
   __syncthreads();
+  __shared__ int s_skip;
   if (t == 0) {
     float m = red[0];
 #pragma unroll
     for (int i = 1; i < INNER_NW; ++i) m = fmaxf(m, red[i]);
     atomicMax(maxcos_bits, __float_as_uint(m));
+    // a pair whose Gram matrix is already diagonal far below the stopping cosine has nothing left to
+    // rotate (the sweeps converge quadratically, so this is the whole last sweep): no solve, and the
+    // apply kernel skips the pair's rows as well
+    s_skip = (m < skip_thr) ? 1 : 0;
+    skip_flags[(size_t)blockIdx.z * gridDim.x + p] = s_skip;
   }
+  __syncthreads();
+  if (s_skip) return;
 
   // thread -> one 2x2 block (k1, k2) of G and two (row, pair) items of R.
   // Every wave computes all 32 rotations of the step redundantly (lanes 0..31)
@@ -366,10 +376,12 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void k_rf_apply(float* __restrict__ aug, const size_t aug_plane_stride,
                                                  const int ld, const int ncols, const int blocks_per_wave,
-                                                 const int2* __restrict__ pairs, const float* __restrict__ Rall) {
+                                                 const int2* __restrict__ pairs, const float* __restrict__ Rall,
+                                                 const int* __restrict__ skip_flags) {
   __shared__ float Rs[RP][RP + 1];      // [k][i]
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, j = lane & 31, h = lane >> 5;
   const int p = blockIdx.x;
+  if (skip_flags[(size_t)blockIdx.z * gridDim.x + p]) return;      // the inner solve found nothing to rotate
   aug += (size_t)blockIdx.z * aug_plane_stride;
   const float* Rp = Rall + ((size_t)blockIdx.z * gridDim.x + p) * RP * RP;
 #pragma unroll
@@ -525,7 +537,7 @@ RefPlan make_plan(int H, int W, int B = 1) {
 }
 
 struct RefWs {           // carved out of ctx->ref_ws; every per-plane array is [B][...]
-  float* aug; float* partials; float* R; int2* pairs; unsigned* maxcos; float* floor2; double* b2; double* q2;
+  float* aug; float* partials; float* R; int2* pairs; unsigned* maxcos; float* floor2; int* skip; double* b2; double* q2;
   float* dvec; int* order; float* scale; float* tmp1; float* tmp2;
 };
 
@@ -537,13 +549,13 @@ int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, 
   const size_t B = (size_t)p.B;
   const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * RP * RP * 4),
                o_R = take(B * p.npairs * RP * RP * 4), o_pairs = take((size_t)p.nsteps * p.npairs * sizeof(int2)),
-               o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
+               o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_skip = take(B * p.npairs * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
                o_d = take(B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
                o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
   WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
   char* b = (char*)ctx->ref_ws;
   w.aug = (float*)(b + o_aug); w.partials = (float*)(b + o_par); w.R = (float*)(b + o_R);
-  w.pairs = (int2*)(b + o_pairs); w.maxcos = (unsigned*)(b + o_mc); w.floor2 = (float*)(b + o_fl); w.b2 = (double*)(b + o_b2);
+  w.pairs = (int2*)(b + o_pairs); w.maxcos = (unsigned*)(b + o_mc); w.floor2 = (float*)(b + o_fl); w.skip = (int*)(b + o_skip); w.b2 = (double*)(b + o_b2);
   w.q2 = (double*)(b + o_q2); w.dvec = (float*)(b + o_d); w.order = (int*)(b + o_ord);
   w.scale = (float*)(b + o_sc); w.tmp1 = (float*)(b + o_t1); w.tmp2 = (float*)(b + o_t2);
   return WM_OK;
@@ -670,10 +682,11 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
       hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch, nz), dim3(256), 0, st, aug, p.aug_ps, p.ld, p.M, pr, par);
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
-                         w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1);
+                         w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1, w.skip + (size_t)z0 * p.npairs,
+                         SKIP_FRACTION * conv_cos);
       const int n_blk = (ncols + 31) / 32, per_wg = 4 * p.apply_tiles;     // 32-column blocks, 4 waves per workgroup
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_blk + per_wg - 1) / per_wg, nz), dim3(256), 0, st,
-                         aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R);
+                         aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R, w.skip + (size_t)z0 * p.npairs);
     }
   };
   while (!done && sweep < MAX_SWEEPS) {
