@@ -39,7 +39,9 @@ constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to 
 // sigma-only calls (extract, detect): row norms are exact to O(cos^2), and the sweep that
 // observes max cos < c still rotates (leaving ~c^2), so they may stop an order earlier (2e-3 already costs 7e-5 relative on dense spectra: tools/ff_sigma_thr.py)
 constexpr float CONV_COS_SIGMA = 2e-4f;
-constexpr float SKIP_FRACTION = 0.25f;    // a block pair below this fraction of the stopping cosine is left alone
+constexpr float SKIP_FRACTION = 0.25f;    // a block pair below this fraction of the (embed) stopping cosine is left alone
+constexpr double RESIDUE_RHO = 10.0;      // |A0 b_i^T| / |b_i|^2 above this: b_i is not a singular direction at all
+constexpr double T_SWITCH = 200.0;        // |A0 b_i^T| / |b_i| is used for s_i >= T_SWITCH * (residual cosine) * s_max
 constexpr int DEFAULT_QUEUES = 2;         // plane groups of a batched Jacobi, each on its own HIP queue
 constexpr double DRIFT_TOL = 1e-2;        // |T[:, i]| / |b_i|^2 may differ from 1 by the scale drift, not more
 constexpr double NULL_ROW_RATIO = 1e-5;   // rows below this fraction of |A|_F do not take part in the convergence test
@@ -237,8 +239,6 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   __shared__ float GG[2][RP][RP + 1];   // double-buffered: a step reads one copy, writes the other
   float (*G)[RP + 1] = GG[0];
   __shared__ float R[RP][RP + 1];
-  __shared__ float WCs[INNER_NW][32], WSs[INNER_NW][32];
-  __shared__ int WPs[INNER_NW][32], WQs[INNER_NW][32];
   __shared__ float red[INNER_NW];
   const int t = threadIdx.x, p = blockIdx.x;
   partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
@@ -305,43 +305,45 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   if (s_skip) return;
 
   // thread -> one 2x2 block (k1, k2) of G and two (row, pair) items of R.
-  // Every wave computes all 32 rotations of the step redundantly (lanes 0..31)
-  // into its own LDS slice, so a step needs ONE workgroup barrier (after the
-  // updates) instead of two.
+  // Every lane computes the rotation of pair (lane & 31) - the wave's two halves redundantly - so
+  // the rotation of the thread's COLUMN pair k2 = t & 31 is already in its registers, and the one
+  // of its ROW pair k1 = t >> 5 (uniform per half-wave) comes from lane k1 by v_readlane: no
+  // rotation table in LDS, one workgroup barrier per step.
   const int k1 = t >> 5, k2 = t & 31;
-  const int wv = t >> 6, lane = t & 63;
-  float* Cw = &WCs[wv][0]; float* Sw_ = &WSs[wv][0];
-  int* Pw = &WPs[wv][0]; int* Qw = &WQs[wv][0];
+  const int wv_s = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool hi = (t & 32) != 0;
   const int n_inner = cross_only ? RB : RP - 1;
   for (int step = 0; step < n_inner; ++step) {
-    if (lane < 32) {
-      const int a = cross_only ? lane : rr_elem(lane, step);
-      const int b = cross_only ? RB + ((lane + step) & (RB - 1)) : rr_elem(RP - 1 - lane, step);
-      const int pp = min(a, b), qq = max(a, b);
-      const float app = G[pp][pp], aqq = G[qq][qq], apq = G[pp][qq];
-      const float tau = aqq - app, g2 = apq + apq;
-      const float ta = fabsf(tau) + 1e-18f;   // all-zero (padding) rows: cos = 1, sin = 0
-      const float ih = __builtin_amdgcn_rsqf(fmaf(g2, g2, ta * ta));   // 1/h, h^2 = tau^2 + 4 apq^2
-      const float x = fmaf(0.5f * ta, ih, 0.5f);                       // cos^2 in [0.5, 1]
-      const float rx = __builtin_amdgcn_rsqf(x);
-      const float c0 = x * rx, s0 = (apq * ih) * rx;                   // cos, sin * sign(apq)
-      const bool sw = tau > 0.0f;                                      // de Rijk: larger diagonal to pp
-      // X[:,p] <- C x_p - S x_q ; X[:,q] <- S x_p + C x_q   (same convention as the tile kernels)
-      Cw[lane] = sw ? s0 : c0;
-      Sw_[lane] = sw ? -c0 : -s0;
-      Pw[lane] = pp; Qw[lane] = qq;
-    }
-    // wave-local hand-off of the rotation table (same wave wrote it): no workgroup barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int a = cross_only ? k2 : rr_elem(k2, step);
+    const int b = cross_only ? RB + ((k2 + step) & (RB - 1)) : rr_elem(RP - 1 - k2, step);
+    const int p2 = min(a, b), q2 = max(a, b);
+    const float app = G[p2][p2], aqq = G[q2][q2], apq = G[p2][q2];
+    const float tau = aqq - app, g2 = apq + apq;
+    const float ta = fabsf(tau) + 1e-18f;   // all-zero (padding) rows: cos = 1, sin = 0
+    const float ih = __builtin_amdgcn_rsqf(fmaf(g2, g2, ta * ta));   // 1/h, h^2 = tau^2 + 4 apq^2
+    const float x = fmaf(0.5f * ta, ih, 0.5f);                       // cos^2 in [0.5, 1]
+    const float rx = __builtin_amdgcn_rsqf(x);
+    float c0 = x * rx, s0 = (apq * ih) * rx;                         // cos, sin * sign(apq)
+    // v_rsq_f32 leaves cos^2 + sin^2 a few 1e-8 off 1, always to the same side: after ~3e4 rotations
+    // the rows' scale has drifted by 1e-4.  One Newton step on the pair's norm removes the bias.
+    const float nrm = fmaf(-0.5f, fmaf(c0, c0, s0 * s0), 1.5f);
+    c0 *= nrm; s0 *= nrm;
+    const bool sw = tau > 0.0f;                                      // de Rijk: larger diagonal to p
+    // X[:,p] <- C x_p - S x_q ; X[:,q] <- S x_p + C x_q   (same convention as the tile kernels)
+    const float C2 = sw ? s0 : c0, S2 = sw ? -c0 : -s0;
+    // row pair k1 = 2 * wave + (lane >> 5): its rotation and indices live in lanes 2 wave, 2 wave + 1
+    // (the builtin moves 32-bit integers: floats go through their bit patterns)
+    const float C1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), 2 * wv_s));
+    const float C1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), 2 * wv_s + 1));
+    const float S1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), 2 * wv_s));
+    const float S1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), 2 * wv_s + 1));
+    const int p1a = __builtin_amdgcn_readlane(p2, 2 * wv_s), p1b = __builtin_amdgcn_readlane(p2, 2 * wv_s + 1);
+    const int q1a = __builtin_amdgcn_readlane(q2, 2 * wv_s), q1b = __builtin_amdgcn_readlane(q2, 2 * wv_s + 1);
+    const float C1 = hi ? C1b : C1a, S1 = hi ? S1b : S1a;
+    const int p1 = hi ? p1b : p1a, q1 = hi ? q1b : q1a;
     float (*Gn)[RP + 1] = GG[(step + 1) & 1];
     // G <- J^T G J on the 2x2 block (rows of pair k1, columns of pair k2)
     {
-      const int p1 = Pw[k1], q1 = Qw[k1];
-      const float C1 = Cw[k1], S1 = Sw_[k1];
-      const int p2 = Pw[k2], q2 = Qw[k2];
-      const float C2 = Cw[k2], S2 = Sw_[k2];
       const float gpp = G[p1][p2], gpq = G[p1][q2], gqp = G[q1][p2], gqq = G[q1][q2];
       const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;   // row p1, columns rotated
       const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;   // row q1
@@ -634,7 +636,12 @@ int get_dct_pair(wm_ctx* ctx, int H, int W, float** dH, float** dW) {
 // block pair (~35 us with most of the chip idle).  With two or more planes the batch is
 // split into two groups on two HIP streams, the second started one gram later, so one
 // group's inner solve runs under the other group's gram/apply tiles.
-int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int* sweeps_out) {
+// what the rotated rows are needed for: their norms only (extract / detect), their directions too (embed:
+// u_i, v_i enter the stego), or the accumulated left factor as well (watermark-side SVD, [A | I])
+enum JacobiUse { JR_SIGMA, JR_EMBED, JR_SVD };
+
+int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse use, int* sweeps_out) {
+  const bool with_q = use == JR_SVD, sigma_only = use == JR_SIGMA;
   const int ncols = with_q ? p.M + p.Lp : p.M;
   int sweep = 0;
   bool done = false;
@@ -647,7 +654,13 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
     return n < 1 ? 1 : (n > 1 + wm_ctx::MAX_AUX ? 1 + wm_ctx::MAX_AUX : n);
   }();
   static const float conv_sigma = getenv("WM_RF_CONV_SIGMA") ? (float)atof(getenv("WM_RF_CONV_SIGMA")) : CONV_COS_SIGMA;
+  // The accumulated factor of JR_SVD needs every rotation; the other two uses stop earlier: a residual
+  // cosine c moves the stego by c * s_max / s_i of a (sub-LSB) term and the singular values by the
+  // bounds documented at fetch_norms_t, the same for embed and extract so that it cancels in S_cw - Sc.
   const float conv_cos = with_q ? CONV_COS : conv_sigma;
+  const float skip_thr = SKIP_FRACTION * conv_cos;
+  (void)sigma_only;
+  ctx->ref_skip_thr = skip_thr;
   const int NQ = std::min(max_queues, p.B);               // group g owns planes [zb[g], zb[g + 1])
   int zb[2 + wm_ctx::MAX_AUX];
   for (int g = 0; g <= NQ; ++g) zb[g] = (int)((long long)g * p.B / NQ);
@@ -683,7 +696,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, int*
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
                          w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1, w.skip + (size_t)z0 * p.npairs,
-                         SKIP_FRACTION * conv_cos);
+                         skip_thr);
       const int n_blk = (ncols + 31) / 32, per_wg = 4 * p.apply_tiles;     // 32-column blocks, 4 waves per workgroup
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_blk + per_wg - 1) / per_wg, nz), dim3(256), 0, st,
                          aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R, w.skip + (size_t)z0 * p.npairs);
@@ -756,15 +769,35 @@ int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0
   // A row that fails this is rounding residue of a rank-deficient plane - its direction is noise,
   // A0 b_i^T measures nothing - and keeps its own (tiny) norm as singular value.
   if (reliable) reliable->assign(b2.size(), 0);
+  // a row below the numerical-null floor (the one the convergence test uses: NULL_ROW_RATIO |A|_F;
+  // rotations preserve the Frobenius norm) whose A0 b_i^T is RESIDUE_RHO times larger than a singular
+  // direction of that norm could give is rounding residue: its singular value is 0, as the float32
+  // cast of LAPACK's 1e-13-sized values would be.  A genuinely small value (clean synthetic images)
+  // has rho near 1 - off by c^2 (s_max / s_i)^2 / 2 at worst - and keeps its norm.
+  std::vector<double> floor2(p.B, 0.0), bmax(p.B, 0.0);
+  for (int z = 0; z < p.B; ++z) {
+    double f2 = 0.0;
+    for (int i = 0; i < p.Lp; ++i) { f2 += b2[(size_t)z * p.Lp + i]; bmax[z] = std::max(bmax[z], b2[(size_t)z * p.Lp + i]); }
+    floor2[z] = NULL_ROW_RATIO * NULL_ROW_RATIO * f2;
+  }
   for (size_t i = 0; i < b2.size(); ++i) {
     const double t2 = q2[i];
-    if (t2 > 0.0 && b2[i] > 0.0) {
-      const double rho = sqrt(t2) / b2[i];
-      if (fabs(rho - 1.0) < DRIFT_TOL) {
-        q2[i] = b2[i] * b2[i] / t2;                                     // sigma = |T[:, i]| / |b_i|
-        if (reliable) (*reliable)[i] = 1;
-      } else q2[i] = 1.0;                                               // sigma = |b_i|
-    } else { b2[i] = 0.0; q2[i] = 1.0; }
+    // |A0 b_i^T| / |b_i| agrees with |b_i| up to the rotations' scale drift unless b_i is residue
+    const double rho = (t2 > 0.0 && b2[i] > 0.0) ? sqrt(t2) / b2[i] : 1e300;
+    const bool consistent = fabs(rho - 1.0) < DRIFT_TOL;
+    if (reliable && consistent) (*reliable)[i] = 1;
+    // Which estimate: with a residual cosine c between rows i and j, |A0 b_i^T| / |b_i| is off by
+    // c^2 (s_j / s_i)^2 / 2 relative, |b_i| by c^2 plus the scale drift (1e-4 relative, i.e. nothing in
+    // absolute terms for a small value).  The Jacobi leaves c <= ref_skip_thr, so the first estimate is
+    // used down to s_i = T_SWITCH * c * s_max (error <= 1.25e-5) and the plain norm below.
+    const double ratio = T_SWITCH * (double)ctx->ref_skip_thr;
+    if (consistent && b2[i] >= ratio * ratio * bmax[i / p.Lp]) {
+      q2[i] = b2[i] * b2[i] / t2;                                       // sigma = |T[:, i]| / |b_i|
+    } else if (rho > RESIDUE_RHO && b2[i] < floor2[i / p.Lp]) {
+      b2[i] = 0.0; q2[i] = 1.0;                                         // residue below the floor: sigma = 0
+    } else {
+      q2[i] = 1.0;                                                      // sigma = |b_i|
+    }
   }
   return WM_OK;
 }
@@ -828,7 +861,7 @@ int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int
                      plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
   WM_TRY(copy_a_part(ctx, p, w, d_a0));
   int sweeps = 0;
-  WM_TRY(jacobi_rows(ctx, p, w, false, &sweeps));
+  WM_TRY(jacobi_rows(ctx, p, w, JR_SIGMA, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2;
   WM_TRY(fetch_norms_t(ctx, p, w, d_a0, d_t, b2, q2));
@@ -873,7 +906,7 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
   WM_TRY(copy_a_part(ctx, p, w, d_yw));
   float* d_t = w.tmp2 + (size_t)n_planes * yw_ps;
   int sweeps = 0;
-  WM_TRY(jacobi_rows(ctx, p, w, false, &sweeps));
+  WM_TRY(jacobi_rows(ctx, p, w, JR_EMBED, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2;
   std::vector<unsigned char> reliable;
@@ -943,7 +976,7 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
   hipLaunchKernelGGL((k_rf_load<float>), dim3(8, p.Lp, 1), dim3(256), 0, ctx->stream, src, src_stride, (size_t)0,
                      p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
   int sweeps = 0;
-  WM_TRY(jacobi_rows(ctx, p, w, true, &sweeps));
+  WM_TRY(jacobi_rows(ctx, p, w, JR_SVD, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
   WM_TRY(fetch_norms(ctx, p, w, true, b2, q2));
