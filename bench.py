@@ -1,8 +1,10 @@
 """bench.py - frames/sec for tile-mode embed + extract on 4K Y-plane frames.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`,
-   one rank per GPU over RCCL)
+  (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ...`
+   or started bare - then this process, before it touches the GPU, starts the N
+   ranks itself as child processes and relays rank 0's JSON line; one rank per
+   GPU over RCCL either way)
 
 One *step* = one pass of the hot path over one batch of synthetic frames that
 are already resident in HBM: per rank, F frames of 2160x3840 uint8 Y ->
@@ -146,8 +148,38 @@ def main_fullframe(a):
     ctx.close()
 
 
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes
+    (torch.distributed.run, rendezvous on 127.0.0.1) from this parent, which has not imported
+    torch or touched HIP, relay rank 0's single JSON line and return the children's status.
+    Never re-execs: a process that has initialised the GPU must not be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    for ln in r.stdout.splitlines():
+        if ln not in lines[-1:]:
+            print(ln, file=sys.stderr)
+    if r.returncode == 0 and not lines:
+        print("[bench] ranks exited 0 but printed no JSON line", file=sys.stderr)
+        return 1
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     if a.mode == "fullframe":
         return main_fullframe(a)
     import torch
@@ -156,8 +188,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if a.same_device:

@@ -157,9 +157,22 @@ def _meta_tile(meta) -> Optional[int]:
     """Tile size a meta was written with: the explicit ``tile`` key, else inferred
     from the singular-value array (per-tile [nby, nbx, 8] vs full-frame [L])."""
     if "tile" in meta:
-        return int(meta["tile"])
+        t = int(meta["tile"])
+        if t == 0:
+            return None
+        if t != TILE:
+            raise ValueError("tile must be 8 or None")
+        return TILE
     s = meta["Sc"] if "Sc" in meta else meta["Sb"]
     return TILE if np.asarray(s).ndim == 3 else None
+
+
+def _check_stego_shape(stego: np.ndarray, meta):
+    """A meta belongs to one stego size (the reference fails later, inside NumPy, with a
+    reshape / matmul error; here the mismatch is named before any device call)."""
+    H, W = map(int, meta["shape"])
+    if tuple(stego.shape[:2]) != (H, W):
+        raise ValueError(f"stego is {stego.shape[1]}x{stego.shape[0]} but the meta was written for {W}x{H}")
 
 
 def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = True,
@@ -183,6 +196,7 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
     if not hg.digests_equal(hg.hmac_digest(key, parts), digest):
         raise ValueError("Sai mật khẩu hoặc meta không khớp.")             # single:208-209,246-247
     tile = _meta_tile(meta)
+    _check_stego_shape(stego, meta)
     ctx = _ctx(device)
     idx = hg.permutation_index(H, W, key)                                  # single:219,265
     if tile is None:
@@ -226,6 +240,7 @@ def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, 
 def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0):
     mode = str(meta["mode"]); alpha = float(meta["alpha"])                 # single:293
     tile = _meta_tile(meta)
+    _check_stego_shape(stego, meta)
     ctx = _ctx(device)
     if tile is None:
         if mode == "gray":

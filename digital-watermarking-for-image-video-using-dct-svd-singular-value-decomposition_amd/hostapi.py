@@ -324,12 +324,16 @@ class Context:
             raise ValueError("stego planes must be uint8")
         n, H, W, rs, ps = _plane_layout(stego)
         nby, nbx = H // TILE, W // TILE
-        sc = np.ascontiguousarray(sigma_c, dtype=np.float32).reshape(n, nby, nbx, 8)
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32)
+        if sc.size != n * nby * nbx * 8:
+            raise ValueError(f"sigma_c has {sc.size} values, the planes need {n}x{nby}x{nbx}x8")
+        sc = sc.reshape(n, nby, nbx, 8)
         Uw = np.ascontiguousarray(Uw, dtype=np.float32)
         Vwt = np.ascontiguousarray(Vwt, dtype=np.float32)
         per_plane = Uw.ndim == 5
-        if Uw.shape[-4:] != (nby, nbx, 8, 8) or Vwt.shape != Uw.shape:
-            raise ValueError("Uw/Vwt shape mismatch")
+        if Uw.ndim not in (4, 5) or Uw.shape[-4:] != (nby, nbx, 8, 8) or Vwt.shape != Uw.shape \
+                or (per_plane and Uw.shape[0] != n):
+            raise ValueError(f"Uw/Vwt shape {Uw.shape}/{Vwt.shape} does not match {n} plane(s) of {nby}x{nbx} tiles")
         if sum_planes:
             tot = np.empty((H, W), np.float32)
             self._call("wm_extract_tiles_sum_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
@@ -348,6 +352,9 @@ class Context:
         sh = np.ascontiguousarray(sw_hat, dtype=np.float32)
         single = Uw.ndim == 4
         n = 1 if single else Uw.shape[0]
+        nby, nbx = H // TILE, W // TILE
+        if Uw.shape[-4:] != (nby, nbx, 8, 8) or Vwt.shape != Uw.shape or sh.size != n * nby * nbx * 8:
+            raise ValueError("Uw / Vwt / sw_hat do not match the plane size")
         out = np.empty((n, H, W), np.float32)
         self._call("wm_reconstruct_tiles", _vp(Uw.ctypes.data), _vp(sh.ctypes.data), _vp(Vwt.ctypes.data),
                    _vp(out.ctypes.data), n, H, W)
@@ -359,9 +366,14 @@ class Context:
             raise ValueError("stego planes must be uint8")
         n, H, W, rs, ps = _plane_layout(stego)
         nby, nbx = H // TILE, W // TILE
-        sc = np.ascontiguousarray(sigma_c, dtype=np.float32).reshape(n, nby, nbx, 8)
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32)
+        if sc.size != n * nby * nbx * 8:
+            raise ValueError(f"sigma_c has {sc.size} values, the planes need {n}x{nby}x{nbx}x8")
+        sc = sc.reshape(n, nby, nbx, 8)
         sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
         per_plane = sw.ndim == 4
+        if sw.ndim not in (3, 4) or sw.shape[-3:] != (nby, nbx, 8) or (per_plane and sw.shape[0] != n):
+            raise ValueError(f"sigma_w shape {sw.shape} does not match {n} plane(s) of {nby}x{nbx} tiles")
         scores = np.zeros(n, np.float64)
         self._call("wm_detect_tiles_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
                    _vp(scores.ctypes.data), n, H, W, rs, ps, nby * nbx * 8 if per_plane else 0, float(alpha))
@@ -470,7 +482,13 @@ class Context:
             raise ValueError("stego plane must be uint8 [H, W]")
         stego = np.ascontiguousarray(stego)
         H, W = stego.shape
+        L = min(H, W)
         sc = np.ascontiguousarray(sigma_c, dtype=np.float32); sw = np.ascontiguousarray(sigma_w, dtype=np.float32)
+        # the C side reads min(H, W) floats from each buffer; the reference would truncate to the
+        # shortest of Sc / S_cw / Sw (single:299,311-313) - a meta that does not belong to this
+        # stego is refused here instead of being read past its end
+        if sc.shape != (L,) or sw.shape != (L,):
+            raise ValueError(f"sigma_c {sc.shape} / sigma_w {sw.shape} do not match the plane's {L} singular values")
         score = C.c_double(0.0)
         self._call("wm_ref_detect_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
                    C.byref(score), H, W, W, float(alpha))

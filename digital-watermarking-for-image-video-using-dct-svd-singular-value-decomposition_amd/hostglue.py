@@ -78,16 +78,16 @@ def ycrcb_to_bgr(ycc: np.ndarray) -> np.ndarray:
 
 
 # ---- watermark resize (single:118) -------------------------------------------
-def _area_matrix(n_src: int, n_dst: int) -> np.ndarray:
+def _area_matrix(n_src: int, n_dst: int, box: bool) -> np.ndarray:
     M = np.zeros((n_dst, n_src), np.float64)
     scale = n_src / n_dst
-    if scale >= 1.0:           # shrink: fractional box coverage
+    if box:                    # shrink: fractional box coverage
         for d in range(n_dst):
             lo, hi = d * scale, (d + 1) * scale
             for s_ in range(int(np.floor(lo)), min(int(np.ceil(hi)), n_src)):
                 M[d, s_] = max(0.0, min(hi, s_ + 1) - max(lo, s_))
             M[d] /= M[d].sum()
-    else:                      # enlarge: INTER_AREA falls back to its linear variant
+    else:                      # INTER_AREA's linear variant (sx = floor(dx*scale), area-style fx)
         inv = 1.0 / scale
         for d in range(n_dst):
             s_ = int(np.floor(d * scale))
@@ -100,13 +100,19 @@ def _area_matrix(n_src: int, n_dst: int) -> np.ndarray:
 
 def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
     """``cv2.resize(img, (W, H), interpolation=cv2.INTER_AREA)`` on uint8.
-    Integer enlargement is pixel replication, integer reduction a box mean."""
+    Integer enlargement is pixel replication, integer reduction a box mean.  cv::resize takes
+    the box filter only when BOTH axes shrink; as soon as one axis enlarges, both axes go
+    through its linear variant (chosen jointly, not per axis).  Parity with OpenCV is unpinned
+    (cv2 is not importable here): OpenCV's 8-bit paths round with cvRound (half to even) after
+    the box filter and use 11-bit fixed-point coefficients in the linear variant; this
+    restatement uses exact weights and round-half-up."""
     h, w = img.shape[:2]
     if (h, w) == (H, W):
         return img.copy()
     if H % h == 0 and W % w == 0:
         return np.repeat(np.repeat(img, H // h, axis=0), W // w, axis=1)
-    My, Mx = _area_matrix(h, H), _area_matrix(w, W)
+    box = h >= H and w >= W
+    My, Mx = _area_matrix(h, H, box), _area_matrix(w, W, box)
     src = img.astype(np.float64)
     if src.ndim == 2:
         out = My @ src @ Mx.T

@@ -356,24 +356,28 @@ def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
 
     Integer up-scale factors reduce to pixel replication and integer
     down-scale factors to box means (round-half-up); other ratios use exact
-    fractional box coverage (down) / the area-variant of linear (up).
+    fractional box coverage when both axes shrink, and the area-variant of linear
+    on BOTH axes as soon as one of them enlarges (cv::resize decides jointly).
+    Unpinned against OpenCV itself (cv2 absent): exact weights, round-half-up.
     """
     h, w = img.shape[:2]
     if (h, w) == (H, W):
         return img.copy()
     src = img.astype(np.float64)
 
+    both_shrink = (h >= H) and (w >= W)
+
     def axis_weights(n_src, n_dst):
         M = np.zeros((n_dst, n_src), np.float64)
         scale = n_src / n_dst
-        if scale >= 1.0:                      # shrinking: fractional box coverage
+        if both_shrink:                       # shrinking: fractional box coverage
             for d in range(n_dst):
                 lo, hi = d * scale, (d + 1) * scale
                 s0 = int(np.floor(lo)); s1 = min(int(np.ceil(hi)), n_src)
                 for s in range(s0, s1):
                     M[d, s] = max(0.0, min(hi, s + 1) - max(lo, s))
                 M[d] /= M[d].sum()
-        else:                                 # enlarging: OpenCV's INTER_AREA-as-linear
+        else:                                 # OpenCV's INTER_AREA-as-linear (either axis enlarges)
             inv = 1.0 / scale
             for d in range(n_dst):
                 s = int(np.floor(d * scale))

@@ -50,3 +50,61 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(root, f), errors="replace").read()
                 assert "wm_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
     assert "oracle" not in open(os.path.join(ge.ROOT, "dct_svd_core_secure.py")).read()
+
+
+class _NoCallContext:
+    """hostapi.Context without a device: any attempt to cross the C ABI fails the test."""
+
+    def __new__(cls, hostapi):
+        ctx = object.__new__(hostapi.Context)
+        ctx._h = None
+
+        def _call(name, *args):
+            raise AssertionError(f"{name} reached the C ABI with unvalidated shapes")
+        ctx._call = _call
+        return ctx
+
+
+def test_meta_shapes_are_validated_before_the_c_abi(hostapi):
+    """a meta that does not belong to the stego (short Sc / Sw, wrong tile grid, per-plane
+    factor batch of another size) must raise ValueError on the host - the C side would read
+    min(H, W) or n_tiles * 8 floats from whatever buffer it is given."""
+    ctx = _NoCallContext(hostapi)
+    st = np.zeros((64, 96), np.uint8)
+    good_sc = np.zeros(64, np.float32)
+    for sc, sw in ((np.zeros(32, np.float32), good_sc), (good_sc, np.zeros(63, np.float32)),
+                   (np.zeros((2, 64), np.float32), good_sc)):
+        with pytest.raises(ValueError):
+            ctx.ref_detect(st, sc, sw, 0.1)
+    nby, nbx = 8, 12
+    sc_t = np.zeros((nby, nbx, 8), np.float32)
+    with pytest.raises(ValueError):
+        ctx.detect_tiles(st, sc_t, np.zeros((nby, nbx - 1, 8), np.float32), 0.1)
+    with pytest.raises(ValueError):
+        ctx.detect_tiles(st, sc_t[:-1], sc_t, 0.1)
+    with pytest.raises(ValueError):
+        ctx.detect_tiles(st, sc_t, np.zeros((2, nby, nbx, 8), np.float32), 0.1)       # per-plane Sw for 1 plane
+    U = np.zeros((nby, nbx, 8, 8), np.float32)
+    with pytest.raises(ValueError):
+        ctx.extract_tiles(st, sc_t, np.zeros((2, nby, nbx, 8, 8), np.float32),
+                          np.zeros((2, nby, nbx, 8, 8), np.float32), 0.1)             # 5-D Uw with shape[0] != n
+    with pytest.raises(ValueError):
+        ctx.extract_tiles(st, sc_t[:4], U, U, 0.1)
+    with pytest.raises(ValueError):
+        ctx.extract_tiles(st, sc_t, U, U[:, :5], 0.1)
+    with pytest.raises(ValueError):
+        ctx.reconstruct_tiles(U, np.zeros((nby, nbx, 4), np.float32), U, 64, 96)
+
+
+def test_meta_tile_and_stego_size_are_checked():
+    import dct_svd_core_secure as core
+    mod = core.embed_arrays.__globals__
+    meta = {"tile": np.int32(16), "Sc": np.zeros((2, 2, 8), np.float32), "shape": np.array((16, 16))}
+    with pytest.raises(ValueError, match="tile must be 8 or None"):
+        mod["_meta_tile"](meta)
+    assert mod["_meta_tile"]({"tile": np.int32(0), "Sc": np.zeros(4)}) is None
+    assert mod["_meta_tile"]({"tile": np.int32(8), "Sc": np.zeros(4)}) == 8
+    assert mod["_meta_tile"]({"Sc": np.zeros((2, 2, 8))}) == 8 and mod["_meta_tile"]({"Sb": np.zeros(16)}) is None
+    with pytest.raises(ValueError, match="meta was written for"):
+        mod["_check_stego_shape"](np.zeros((16, 24, 3), np.uint8), meta)
+    mod["_check_stego_shape"](np.zeros((16, 16, 3), np.uint8), meta)

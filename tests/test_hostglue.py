@@ -17,7 +17,7 @@ def test_colour_and_resize_match_oracle():
     assert np.array_equal(hg.bgr_to_gray(a), o.bgr_to_gray(a))
     assert np.array_equal(hg.bgr_to_ycrcb(a), o.bgr_to_ycrcb(a))
     assert np.array_equal(hg.ycrcb_to_bgr(a), o.ycrcb_to_bgr(a))
-    for (W, H) in ((112, 80), (28, 20), (50, 33), (56, 40)):
+    for (W, H) in ((112, 80), (28, 20), (50, 33), (56, 40), (28, 80), (70, 25)):   # last two: one axis shrinks, one enlarges
         assert np.array_equal(hg.resize_area(a, W, H), o.resize_area(a, W, H)), (W, H)
     # known answers: saturation + exact grey
     px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 0, 255]]], np.uint8)
