@@ -74,3 +74,23 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_run(tmp_path, gpu_ctx):
     assert np.array_equal(np.concatenate([r[0]["stego"], r[1]["stego"]]), st)
     assert np.array_equal(np.concatenate([r[0]["sc"], r[1]["sc"]]).reshape(sc.shape), sc)
     assert np.array_equal(np.concatenate([r[0]["wm"], r[1]["wm"]]), wm)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent (which never touches the GPU)
+    starts two ranks as child processes, rank 0's single JSON line comes back with n_gpus == 2.
+    gloo + --same-device because the test box has one GPU; the driver's node runs the same code over RCCL."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+                        "--height", "64", "--width", "96", "--frames", "4", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["value"] > 0 and j["config"]["frames_per_rank"] == 4
+    assert "roofline" in j and j["roofline"]["achieved"] > 0

@@ -76,3 +76,21 @@ def test_gloo_world2_broadcast_and_ranges(tmp_path):
     assert (r0[0], r0[1], r1[0], r1[1]) == (0, 2, 2, 5)
     assert r0[2] == r1[2] and r0[2] > 0                    # rank 1 received rank 0's singular values
     assert abs(r0[3] - r1[3]) < 1e-9 and r0[3] > 0         # all-gathered report agrees on both ranks
+
+
+def test_bench_launcher_fails_loudly_without_gpus():
+    """No GPU here: `bench.py --gpus 2` must still start its two ranks itself (each says it needs a GPU)
+    and hand their failure back as a non-zero status - never a silent single-rank measurement."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--height", "64", "--width", "96",
+                        "--frames", "2", "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=env, timeout=300, cwd=root)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-1500:]
