@@ -30,6 +30,7 @@ int set_err(int code, const char* fmt, const char* a = "", const char* b = "");
 
 struct wm_ctx {
   int device = 0;
+  int n_cu = 256;                 // multiProcessorCount of the device (persistent grids are sized from it)
   hipStream_t stream = nullptr;
   bool owns_stream = false;
   int* d_status = nullptr;        // [0] sticky kernel status, [1] embed fallback count

@@ -148,6 +148,12 @@ constexpr int JAC_MAX_SWEEPS = 12;
 // threshold from 1e-7 to 1e-3) with 4.1 instead of 5.0 sweeps per wave.  The embed keeps
 // JAC_CONV2: its reconstruction needs the VECTORS (B orthogonal to 1e-7).
 constexpr float JAC_CONV2_SIGMA = 1e-3f;
+// From the 5th sweep on the embed's sweeps test every pair before rotating it: by then 93 % of the
+// pair visits are below cos^2 = 1e-12 in all 64 tiles of a wave (tools/skip_study.cpp), i.e. the 5th
+// sweep is almost pure verification, and a skipped pair costs its dot product only.  1e-12 is
+// cos = 1e-6, an order above the float32 floor the full sweeps end at (1.2e-7): measured against the
+// round-1 kernel the stego differs by 1 LSB on 4.5e-6 of the pixels (profiles/r02_embed_variants.md).
+constexpr float JAC_SKIP2 = 1e-12f;
 
 template <bool WITH_V>
 WM_HD void jacobi_rot(float (&a)[8][8], float (&v)[8][8], float (&n2)[8],
@@ -287,7 +293,7 @@ constexpr float SIGMA_RATIO_MIN2 = 1e-10f;   // (s_8 / s_1)^2 below this -> lite
 // one Jacobi rotation of columns p,q (no V).  c0 = cos, s0 = sin*sign(g) from
 // two v_rsq_f32:  cos^2 = (1 + |tau|/h)/2,  sin = g / (h cos),  h^2 = tau^2+4g^2.
 // CHECK: 0 = no convergence test, 1 = JAC_CONV2 (vectors needed), 2 = JAC_CONV2_SIGMA.
-template <int CHECK>
+template <int CHECK, bool SKIP = false>
 WM_HD void jacobi_rot_pk(v2f (&a)[4][8], float (&n2)[8], const int p, const int q, bool& notconv) {
   v2f gv = a[0][p] * a[0][q];
 #pragma unroll
@@ -295,6 +301,9 @@ WM_HD void jacobi_rot_pk(v2f (&a)[4][8], float (&n2)[8], const int p, const int 
   const float g = gv[0] + gv[1];
   const float al = n2[p], be = n2[q];
   if (CHECK) notconv = notconv || (g * g > (CHECK == 2 ? JAC_CONV2_SIGMA : JAC_CONV2) * (al * be));
+  // late sweeps: a pair that is below JAC_SKIP2 (cos^2) in every tile of the wave is left alone
+  // (wave-uniform branch; the dot product and the test are all it costs)
+  if (SKIP && !wave_any(g * g > JAC_SKIP2 * (al * be))) return;
   const float tau = be - al;
   const float ta = fabsf(tau) + 1e-18f;          // keeps 0/0 out: g == 0 -> cos = 1 exactly
   const float g2 = g + g;
@@ -329,12 +338,12 @@ WM_HD void col_norms2_pk(const v2f (&a)[4][8], float (&n2)[8]) {
 
 // B = X V with orthogonal columns sorted by norm; n2 = |b_i|^2.  Returns the
 // sweep count (negative: bound hit).
-template <int CHECK>
+template <int CHECK, bool SKIP = false>
 WM_HD void jacobi_sweep_pk(v2f (&a)[4][8], float (&n2)[8], bool& notconv) {
 #pragma unroll
   for (int p = 0; p < 7; ++p)
 #pragma unroll
-    for (int q = p + 1; q < 8; ++q) jacobi_rot_pk<CHECK>(a, n2, p, q, notconv);
+    for (int q = p + 1; q < 8; ++q) jacobi_rot_pk<CHECK, SKIP>(a, n2, p, q, notconv);
 }
 
 template <bool SIGMA_ONLY = false>
@@ -348,10 +357,23 @@ WM_HD int jacobi_cols_pk(v2f (&a)[4][8], float (&n2)[8]) {
   jacobi_sweep_pk<0>(a, n2, notconv);
   jacobi_sweep_pk<0>(a, n2, notconv);
   int sweep = 2;
+#if !defined(WM_EXP_R1_SWEEPS)
+  // The embed's third sweep carries no test either: no image or noise tile is done after three
+  // sweeps at cos^2 <= 1e-7 (tools/skip_study.cpp: 0 of 19 200), so the earliest last sweep is the 4th.
+  if (!SIGMA_ONLY) {
+    col_norms2_pk(a, n2);
+    jacobi_sweep_pk<0>(a, n2, notconv);
+    sweep = 3;
+  }
+#endif
   bool more = true;
   while (more && sweep < JAC_MAX_SWEEPS) {
     if ((sweep & 1) == 0) col_norms2_pk(a, n2);
     notconv = false;
+#if !defined(WM_EXP_R1_SWEEPS)
+    if (!SIGMA_ONLY && sweep >= 4) jacobi_sweep_pk<1, true>(a, n2, notconv);
+    else
+#endif
     jacobi_sweep_pk<SIGMA_ONLY ? 2 : 1>(a, n2, notconv);
     ++sweep;
     more = wave_any(notconv);

@@ -208,21 +208,52 @@ __device__ __forceinline__ bool tile_coords(const Geom& g, int& t, int& ty, int&
   return true;
 }
 
+// Plane-fastest, XCD-aware order for kernels whose planes SHARE per-tile inputs (the frames of a
+// clip share Ux / Vxt: 512 B per tile).  Workgroups are dealt round-robin over the 8 XCDs, so
+// b and b + 8 share an L2 (observed placement - it only affects speed, never results).  XCD x
+// walks tile groups x, x + 8, ... and, for each group, all planes back to back: the group's
+// shared inputs come from HBM once and are served to the other planes by that XCD's L2, instead
+// of once per plane (grid (groups, planes): 66 MB of factors re-fetched 32 times at 32 x 4K).
+constexpr unsigned N_XCD = 8;
+__device__ __forceinline__ bool tile_coords_planefast(const Geom& g, const unsigned n_planes, int& t, int& ty,
+                                                      int& tx, size_t& plane) {
+#if defined(WM_EXP_EXTRACT_OLDMAP)   // A/B only: the round-1 order (all tile groups of plane 0, then plane 1, ...)
+  const unsigned per_plane = gridDim.x / n_planes;
+  const unsigned grp = blockIdx.x % per_plane;
+  plane = blockIdx.x / per_plane;
+#else
+  const unsigned b = blockIdx.x, x = b % N_XCD, k = b / N_XCD;
+  const unsigned grp = x + N_XCD * (k / n_planes);
+  plane = k % n_planes;
+#endif
+  t = (int)(grp * WAVE + threadIdx.x);
+  if (t >= g.n_tiles) return false;
+  ty = t / g.nbx;
+  tx = t - ty * g.nbx;
+  return true;
+}
+inline dim3 tile_grid_planefast(const Geom& g, int n_planes) {
+  const size_t groups = ((size_t)g.n_tiles + WAVE - 1) / WAVE;
+  const size_t per_xcd = (groups + N_XCD - 1) / N_XCD;
+  return dim3((unsigned)(per_xcd * N_XCD * (size_t)n_planes), 1, 1);
+}
+
 // ---------------------------------------------------------------------------
 // K1  fused embed   (a1 a2 a3 a4 a5 a6 a7; sigma_c side output)
 // ---------------------------------------------------------------------------
 // Fast path: packed, V-free, pixel-domain (wm_tile_math.h identities (1),(2)).
 // Flat / rank-deficient tiles append their id to `fb_list` (count = status[1])
 // and are redone by k_embed_fallback.
+#ifndef WM_EMBED_WAVES
+#define WM_EMBED_WAVES 3
+#endif
 template <bool ALIGNED, bool YW>
-__global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
+__device__ __forceinline__ void embed_group(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
-    const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status, uint32_t* __restrict__ fb_list) {
-  int t, ty, tx;
-  if (!tile_coords(g, t, ty, tx)) return;
-  const size_t plane = blockIdx.y;
+    const Geom& g, const size_t sw_plane_stride, const float alpha, const int K,
+    int* __restrict__ status, uint32_t* __restrict__ fb_list,
+    const int t, const int ty, const int tx, const size_t plane) {
   const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
 
   wm::v2f a[4][8];
@@ -273,6 +304,26 @@ __global__ __launch_bounds__(WAVE, 3) void k_embed_tiles(
     if (!deficient) store_words<ALIGNED>(stego + off + 4 * half, g.row_stride, ow);
     asm volatile("" ::: "memory");
   }
+}
+
+// One wave per workgroup and one workgroup per (tile group, plane): 64 800 workgroups per
+// 32 x 4K launch.  A persistent grid (CUs x resident waves, grid-stride over the work) was
+// measured 4 % SLOWER in the same process (profiles/r02_embed_variants.md): the dispatcher's
+// dynamic placement balances waves that need 4 against waves that need 5 sweeps, a fixed
+// stride does not.
+template <bool ALIGNED, bool YW>
+__global__ __launch_bounds__(WAVE, WM_EMBED_WAVES) void k_embed_tiles(
+    const uint8_t* host, const float* __restrict__ sigma_w,
+    uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
+    const Geom g, const unsigned n_groups, const size_t sw_plane_stride,
+    const float alpha, const int K, int* __restrict__ status, uint32_t* __restrict__ fb_list) {
+  const unsigned w = blockIdx.x;
+  const unsigned plane = w / n_groups, grp = w - plane * n_groups;
+  const int t = (int)(grp * WAVE + threadIdx.x);
+  if (t >= g.n_tiles) return;
+  const int ty = t / g.nbx, tx = t - ty * g.nbx;
+  embed_group<ALIGNED, YW>(host, sigma_w, stego, sigma_c, yw, g, sw_plane_stride, alpha, K, status, fb_list,
+                           t, ty, tx, (size_t)plane);
 }
 
 // Literal chain with orthonormal completion (wm::embed_tile_completed) for the
@@ -390,11 +441,11 @@ template <bool ALIGNED, bool VECF, bool PX>
 __global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
     const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
     const float* __restrict__ Uw, const float* __restrict__ Vwt, float* __restrict__ out,
-    const Geom g, const size_t uv_plane_stride, const float inv_alpha, const int K,
+    const Geom g, const unsigned n_planes, const size_t uv_plane_stride, const float inv_alpha, const int K,
     int* __restrict__ status) {
   int t, ty, tx;
-  if (!tile_coords(g, t, ty, tx)) return;
-  const size_t plane = blockIdx.y;
+  size_t plane;
+  if (!tile_coords_planefast(g, n_planes, t, ty, tx, plane)) return;
   wm::RawTile raw;
   float a[8][8], s[8], sc[8], keep[8];
   load_raw<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
@@ -622,6 +673,11 @@ int wm_create(int device, void* stream, wm_ctx** ctx_out) {
   wm_ctx* ctx = new (std::nothrow) wm_ctx();
   if (!ctx) return set_err(WM_ERR_NOMEM, "host allocation failed");
   ctx->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cu = cus;
+    else (void)hipGetLastError();
+  }
   if (stream) {
     ctx->stream = (hipStream_t)stream;
   } else {
@@ -742,7 +798,11 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
     if ((((uintptr_t)sigma_w | (uintptr_t)sigma_c) & 15u) || (sigma_w_plane_stride & 3u))
       return set_err(WM_ERR_BADARG, "sigma arrays must be 16-byte aligned");
     const bool al = u8_aligned(host, stego, row_stride, plane_stride);
-    const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+    const dim3 block(WAVE);
+    const unsigned n_groups = (unsigned)((g.n_tiles + WAVE - 1) / WAVE);
+    const size_t n_work_sz = (size_t)n_groups * (size_t)n_planes;
+    if (n_work_sz > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 tile groups in one call");
+    const dim3 grid((unsigned)n_work_sz);
     const size_t n_all = (size_t)g.n_tiles * (size_t)n_planes;
     if (n_all > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 tiles in one call");   // ids are uint32, the device-side count an int
     const size_t n_waves = (n_all + WAVE - 1) / WAVE;
@@ -753,7 +813,8 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
 #define WM_LAUNCH_EMBED(A, Y)                                                                      \
   do {                                                                                             \
     hipLaunchKernelGGL((k_embed_tiles<A, Y>), grid, block, 0, ctx->stream, host, sigma_w, stego,   \
-                       sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb);         \
+                       sigma_c, yw, g, n_groups, sigma_w_plane_stride, alpha, K,                   \
+                       ctx->d_status, fb);                                                          \
     hipLaunchKernelGGL((k_embed_fallback<A, Y>), fgrid, block, 0, ctx->stream, host, sigma_w,      \
                        stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb);  \
   } while (0)
@@ -827,10 +888,12 @@ static int extract_tiles_dev(wm_ctx* ctx, const uint8_t* stego, const float* sig
   const float inv_alpha = 1.0f / fmaxf(alpha, 1e-8f);
   const bool al = u8_aligned(stego, stego, row_stride, plane_stride);
   const bool vf = f32_vec_ok(out, (size_t)W, g.HW);
-  const dim3 grid = tile_grid(g, n_planes), block(WAVE);
+  if ((((size_t)g.n_tiles + WAVE - 1) / WAVE + N_XCD) * (size_t)n_planes > 0x7fffffffull)
+    return set_err(WM_ERR_BADARG, "more than 2^31 tile groups in one call");
+  const dim3 grid = tile_grid_planefast(g, n_planes), block(WAVE);
 #define WM_LAUNCH_EXTRACT(A, V, P)                                                                    \
   hipLaunchKernelGGL((k_extract_tiles<A, V, P>), grid, block, 0, ctx->stream, stego, sigma_c, Uw, Vwt, \
-                     out, g, uv_plane_stride, inv_alpha, K, ctx->d_status)
+                     out, g, (unsigned)n_planes, uv_plane_stride, inv_alpha, K, ctx->d_status)
   if (px) {
     if (al && vf) WM_LAUNCH_EXTRACT(true, true, true);
     else if (al) WM_LAUNCH_EXTRACT(true, false, true);
