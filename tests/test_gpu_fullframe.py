@@ -208,3 +208,60 @@ def test_fullframe_batch_of_mixed_content(gpu_ctx):
         s1, c1, y1 = gpu_ctx.ref_embed(planes[z], Sw, 0.15, 57, want_yw=True)
         assert np.abs(st[z].astype(int) - s1.astype(int)).max() <= 1, z
         assert np.abs(yw[z] - y1).max() < 2e-2, z
+
+
+def test_fullframe_cfg2_1080p_against_float64_lapack(gpu_ctx):
+    """BASELINE config 2's shape (1920x1080 Y, alpha = 0.15) in the reference's own semantics:
+    embed, sigma, extract and detect of one full-size plane against the oracle (float64 LAPACK),
+    same tolerances as the small shapes.  The block-Jacobi's estimate policy (T = A0 B^T above
+    1e-2 sigma_1, row norms below), its skip flags and its stopping cosine were tuned at this size."""
+    H, W, alpha, kfrac = 1080, 1920, 0.15, 0.6
+    host, wys = _inputs(H, W)
+    ref = o.embed_plane(host.astype(np.float32), wys, alpha, kfrac, tile=None)
+    K = ref["K"]
+    assert K == 648
+    stego, sc, yw = gpu_ctx.ref_embed(host, ref["Sw"], alpha, K, want_yw=True)
+    assert np.max(np.abs(sc - ref["Sc"])) / ref["Sc"][0] < 2e-6
+    d = np.abs(stego.astype(int) - ref["stego"].astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+    assert np.abs(yw - ref["Yw"]).max() < 2e-2
+    s = gpu_ctx.ref_sigma(ref["stego"])
+    so = o.stego_sigma(ref["stego"].astype(np.float32), None)
+    assert np.max(np.abs(s - so)) / so[0] < 2e-6
+    # per value above the estimate switch (1e-2 sigma_1, decided on the drifted row norms: a value within
+    # 1e-4 of the switch may fall on either side - at this size the smallest of the bulk sits right on it)
+    big = so > 1.1e-2 * so[0]
+    assert np.max(np.abs(s - so)[big] / so[big]) < 2e-5
+    score = gpu_ctx.ref_detect(ref["stego"], ref["Sc"], ref["Sw"], alpha)
+    assert abs(score - o.detect_plane(ref["stego"].astype(np.float32), ref["Sc"], ref["Sw"], alpha, None)) < 2e-3
+    w = gpu_ctx.ref_extract(ref["stego"], ref["Sc"], ref["Uw"], ref["Vwt"], alpha, K)
+    wo = o.extract_plane(ref["stego"].astype(np.float32), ref["Sc"], ref["Uw"], ref["Vwt"], alpha, kfrac, H, W, None)
+    assert np.abs(w - wo).max() < 2e-3 * np.abs(wo).max()
+    # the watermark-side decomposition at full size (once per watermark in the product)
+    U, S, Vt = gpu_ctx.ref_svd(wys, apply_dct=True)
+    assert np.max(np.abs(S - ref["Sw"])) / ref["Sw"][0] < 1e-4
+    L = min(H, W)
+    assert np.abs(U.T @ U - np.eye(L)).max() < 2e-4 and np.abs(Vt @ Vt.T - np.eye(L)).max() < 2e-4
+
+
+def test_fullframe_1080p_batch_of_three(gpu_ctx):
+    """Three 1080p planes (the B, G, R planes of a colour image / three frames) through ONE batched call:
+    singular values against float64 LAPACK, stego against the single-plane path, detect per plane."""
+    H, W, alpha = 1080, 1920, 0.15
+    rng = np.random.default_rng(21)
+    hosts = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    Sw = np.sort(rng.uniform(5, 4e4, H).astype(np.float32))[::-1].copy()
+    K = 648
+    st, sc, _ = gpu_ctx.ref_embed_planes(hosts, Sw, alpha, K)
+    for z in range(3):
+        ref = np.linalg.svd(hosts[z].astype(np.float64), compute_uv=False)
+        assert np.abs(sc[z] - ref).max() < 2e-6 * ref[0], z
+    s1, c1, _ = gpu_ctx.ref_embed(hosts[1], Sw, alpha, K)
+    assert np.abs(st[1].astype(int) - s1.astype(int)).max() <= 1 and np.mean(st[1] != s1) < 2e-3
+    assert np.max(np.abs(sc[1] - c1)) < 1e-5 * c1[0]
+    scores = gpu_ctx.ref_detect_planes(st, sc, Sw, alpha)
+    assert scores.shape == (3,) and scores.min() > 0.9
+    # sigma(stego)[:K] = Sc[:K] + alpha Sw[:K] up to the uint8 quantisation of the stego (single:174-176)
+    sig = gpu_ctx.ref_sigma_planes(st)
+    got = (sig[:, :K] - sc[:, :K]) / alpha
+    assert np.corrcoef(got[0], Sw[:K])[0, 1] > 0.99
