@@ -42,6 +42,12 @@ struct wm_ctx {
   size_t fb_bytes = 0;
   void* ref_ws = nullptr;         // grow-only workspace of the full-frame mode
   size_t ref_ws_bytes = 0;
+  void* ref_ws2 = nullptr;        // second one: null-space completion of rank-deficient planes
+  size_t ref_ws2_bytes = 0;
+  static constexpr int MAX_PAIR_TABS = 6;   // round-robin tournaments of the block Jacobi, by block count
+  void* pair_tab[MAX_PAIR_TABS] = {};
+  int pair_tab_nbk[MAX_PAIR_TABS] = {};
+  int pair_tab_next = 0;
   float* dct_mat[2] = {nullptr, nullptr};   // cached DCT-II basis matrices (device), by size
   int dct_n[2] = {0, 0};
   int ref_last_sweeps = 0;        // outer Jacobi sweeps of the last full-frame SVD (diagnostics)

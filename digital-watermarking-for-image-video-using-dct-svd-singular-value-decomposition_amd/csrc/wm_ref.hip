@@ -59,10 +59,11 @@ typedef float v16f_s __attribute__((ext_vector_type(16)));
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_sgemm(const int M, const int N, const int K, const float alpha,
-                                              const float* __restrict__ A, const int lda,
-                                              const float* __restrict__ B, const int ldb,
-                                              const float beta, float* __restrict__ C, const int ldc) {
+                                              const float* __restrict__ A, const int lda, const size_t sA,
+                                              const float* __restrict__ B, const int ldb, const size_t sB,
+                                              const float beta, float* __restrict__ C, const int ldc, const size_t sC) {
   constexpr int KS = 32;
+  A += (size_t)blockIdx.z * sA; B += (size_t)blockIdx.z * sB; C += (size_t)blockIdx.z * sC;   // batch: one product per grid.z
   __shared__ float As[2][64][KS + 1];   // [m][k]
   __shared__ float Bs[2][KS][64 + 1];   // [k][n]
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, j = lane & 31, h = lane >> 5;
@@ -126,16 +127,22 @@ __global__ __launch_bounds__(256) void k_sgemm(const int M, const int N, const i
   }
 }
 
-int sgemm(wm_ctx* ctx, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda,
-          const float* B, int ldb, float beta, float* C, int ldc) {
-  if (M <= 0 || N <= 0) return WM_OK;
-  const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-  if (ta && tb) hipLaunchKernelGGL((k_sgemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-  else if (ta) hipLaunchKernelGGL((k_sgemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-  else if (tb) hipLaunchKernelGGL((k_sgemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-  else hipLaunchKernelGGL((k_sgemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+// `batch` products per launch (grid.z); sA / sB / sC = elements between consecutive operands (0: shared)
+int sgemm_b(wm_ctx* ctx, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, size_t sA,
+            const float* B, int ldb, size_t sB, float beta, float* C, int ldc, size_t sC, int batch) {
+  if (M <= 0 || N <= 0 || batch <= 0) return WM_OK;
+  const dim3 grid((N + 63) / 64, (M + 63) / 64, batch), block(256);
+  if (ta && tb) hipLaunchKernelGGL((k_sgemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+  else if (ta) hipLaunchKernelGGL((k_sgemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+  else if (tb) hipLaunchKernelGGL((k_sgemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+  else hipLaunchKernelGGL((k_sgemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
   WM_HIP(hipGetLastError());
   return WM_OK;
+}
+
+int sgemm(wm_ctx* ctx, bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda,
+          const float* B, int ldb, float beta, float* C, int ldc) {
+  return sgemm_b(ctx, ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -476,14 +483,6 @@ __global__ void k_rf_scale_rows(float* __restrict__ aug, const size_t aug_plane_
     aug[(size_t)i * ld + j] *= s;
 }
 
-// dst[r][k] = src[r][k] * d[k]   (L x L, "U @ diag(d)")
-__global__ void k_rf_scale_cols(const float* __restrict__ src, float* __restrict__ dst, const int L,
-                                const float* __restrict__ d) {
-  const int r = blockIdx.y;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < L; k += gridDim.x * blockDim.x)
-    dst[(size_t)r * L + k] = src[(size_t)r * L + k] * d[k];
-}
-
 // Yw (float, logical A layout L x M or its transpose) -> clip/truncate -> uint8 plane; optional float copy
 __global__ void k_rf_quant(const float* __restrict__ yw, const size_t yw_plane_stride, const int ldy,
                            const int transpose, uint8_t* __restrict__ dst, const size_t dst_stride,
@@ -508,6 +507,26 @@ __global__ void k_rf_gather_rows(const float* __restrict__ src, const int ld, co
   const float s = scale[k];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ncols; j += gridDim.x * blockDim.x)
     dst[(size_t)k * ldd + j] = row[j] * s;
+}
+
+// deterministic pseudo-random pattern in (-1, 1): the start vectors of the null-space completion
+// (rank-deficient planes); element (r, c) of the matrix with seed `seed`
+__global__ void k_rf_pattern(float* __restrict__ dst, const int rows, const int cols, const unsigned seed) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)r * 0x9E3779B1u ^ ((unsigned)c + seed) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    dst[(size_t)r * cols + c] = (float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+  }
+}
+
+// dst[r][k] = src[r][k] * d[k]   (rows x cols, dense, batch = grid.z with strides)
+__global__ void k_rf_scale_cols_b(const float* __restrict__ src, const size_t s_src, float* __restrict__ dst,
+                                  const size_t s_dst, const int cols, const float* __restrict__ d, const size_t s_d) {
+  const int r = blockIdx.y;
+  src += (size_t)blockIdx.z * s_src; dst += (size_t)blockIdx.z * s_dst; d += (size_t)blockIdx.z * s_d;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cols; k += gridDim.x * blockDim.x)
+    dst[(size_t)r * cols + k] = src[(size_t)r * cols + k] * d[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -538,32 +557,26 @@ RefPlan make_plan(int H, int W, int B = 1) {
   return p;
 }
 
-struct RefWs {           // carved out of ctx->ref_ws; every per-plane array is [B][...]
-  float* aug; float* partials; float* R; int2* pairs; unsigned* maxcos; float* floor2; int* skip; double* b2; double* q2;
+struct RefWs {           // carved out of a grow-only context buffer; every per-plane array is [B][...]
+  float* aug; float* partials; float* R; const int2* pairs; unsigned* maxcos; float* floor2; int* skip; double* b2; double* q2;
   float* dvec; int* order; float* scale; float* tmp1; float* tmp2;
 };
 
 inline size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, size_t extra_f32_b) {
-  size_t off = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off += a256(bytes); return o; };
-  const size_t B = (size_t)p.B;
-  const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * RP * RP * 4),
-               o_R = take(B * p.npairs * RP * RP * 4), o_pairs = take((size_t)p.nsteps * p.npairs * sizeof(int2)),
-               o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_skip = take(B * p.npairs * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
-               o_d = take(B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
-               o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
-  WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
-  char* b = (char*)ctx->ref_ws;
-  w.aug = (float*)(b + o_aug); w.partials = (float*)(b + o_par); w.R = (float*)(b + o_R);
-  w.pairs = (int2*)(b + o_pairs); w.maxcos = (unsigned*)(b + o_mc); w.floor2 = (float*)(b + o_fl); w.skip = (int*)(b + o_skip); w.b2 = (double*)(b + o_b2);
-  w.q2 = (double*)(b + o_q2); w.dvec = (float*)(b + o_d); w.order = (int*)(b + o_ord);
-  w.scale = (float*)(b + o_sc); w.tmp1 = (float*)(b + o_t1); w.tmp2 = (float*)(b + o_t2);
-  return WM_OK;
-}
-
-int upload_pairs(wm_ctx* ctx, const RefPlan& p, const RefWs& w) {
+// The round-robin tournament of a plan depends on its block count only: built once per context and
+// block count (a handful of sizes per process), kept on the device, handed out without a copy or a sync.
+int get_pairs(wm_ctx* ctx, const RefPlan& p, const int2** out) {
+  for (int i = 0; i < wm_ctx::MAX_PAIR_TABS; ++i)
+    if (ctx->pair_tab[i] && ctx->pair_tab_nbk[i] == p.nbk) { *out = (const int2*)ctx->pair_tab[i]; return WM_OK; }
+  int slot = -1;
+  for (int i = 0; i < wm_ctx::MAX_PAIR_TABS; ++i) if (!ctx->pair_tab[i]) { slot = i; break; }
+  if (slot < 0) {                                   // full: recycle round-robin (nothing in flight may still read it)
+    slot = ctx->pair_tab_next; ctx->pair_tab_next = (ctx->pair_tab_next + 1) % wm_ctx::MAX_PAIR_TABS;
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    WM_HIP(hipFree(ctx->pair_tab[slot]));
+    ctx->pair_tab[slot] = nullptr;
+  }
   std::vector<int2> tab((size_t)p.nsteps * p.npairs);
   std::vector<int> idx(p.nbk);
   std::iota(idx.begin(), idx.end(), 0);
@@ -576,8 +589,39 @@ int upload_pairs(wm_ctx* ctx, const RefPlan& p, const RefWs& w) {
     for (int j = p.nbk - 1; j > 1; --j) idx[j] = idx[j - 1];
     idx[1] = last;
   }
-  WM_HIP(hipMemcpyAsync(w.pairs, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-  WM_HIP(hipStreamSynchronize(ctx->stream));     // tab is a local
+  if (hipMalloc(&ctx->pair_tab[slot], std::max<size_t>(tab.size(), 1) * sizeof(int2)) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->pair_tab[slot] = nullptr;
+    return set_err(WM_ERR_NOMEM, "hipMalloc failed for %s", "pair table");
+  }
+  if (!tab.empty()) {
+    WM_HIP(hipMemcpyAsync(ctx->pair_tab[slot], tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));     // tab is a local
+  }
+  ctx->pair_tab_nbk[slot] = p.nbk;
+  *out = (const int2*)ctx->pair_tab[slot];
+  return WM_OK;
+}
+
+// which = 0: the context's main full-frame workspace; 1: the second one (null-space completion, so that the
+// first call's arrays stay where they are)
+int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, size_t extra_f32_b, int which = 0) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += a256(bytes); return o; };
+  const size_t B = (size_t)p.B;
+  const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * RP * RP * 4),
+               o_R = take(B * p.npairs * RP * RP * 4),
+               o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_skip = take(B * p.npairs * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
+               o_d = take(B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
+               o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
+  if (which == 0) WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
+  else WM_TRY(grow(ctx, &ctx->ref_ws2, &ctx->ref_ws2_bytes, off, "full-frame completion workspace"));
+  char* b = (char*)(which == 0 ? ctx->ref_ws : ctx->ref_ws2);
+  w.aug = (float*)(b + o_aug); w.partials = (float*)(b + o_par); w.R = (float*)(b + o_R);
+  w.maxcos = (unsigned*)(b + o_mc); w.floor2 = (float*)(b + o_fl); w.skip = (int*)(b + o_skip); w.b2 = (double*)(b + o_b2);
+  w.q2 = (double*)(b + o_q2); w.dvec = (float*)(b + o_d); w.order = (int*)(b + o_ord);
+  w.scale = (float*)(b + o_sc); w.tmp1 = (float*)(b + o_t1); w.tmp2 = (float*)(b + o_t2);
+  WM_TRY(get_pairs(ctx, p, &w.pairs));
   return WM_OK;
 }
 
@@ -638,7 +682,8 @@ int get_dct_pair(wm_ctx* ctx, int H, int W, float** dH, float** dW) {
 // group's inner solve runs under the other group's gram/apply tiles.
 // what the rotated rows are needed for: their norms only (extract / detect), their directions too (embed:
 // u_i, v_i enter the stego), or the accumulated left factor as well (watermark-side SVD, [A | I])
-enum JacobiUse { JR_SIGMA, JR_EMBED, JR_SVD };
+// JR_ORTH: orthogonalise the rows only (null-space completion): no left factor, the tight stopping cosine
+enum JacobiUse { JR_SIGMA, JR_EMBED, JR_SVD, JR_ORTH };
 
 int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse use, int* sweeps_out) {
   const bool with_q = use == JR_SVD, sigma_only = use == JR_SIGMA;
@@ -657,7 +702,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
   // The accumulated factor of JR_SVD needs every rotation; the other two uses stop earlier: a residual
   // cosine c moves the stego by c * s_max / s_i of a (sub-LSB) term and the singular values by the
   // bounds documented at fetch_norms_t, the same for embed and extract so that it cancels in S_cw - Sc.
-  const float conv_cos = with_q ? CONV_COS : conv_sigma;
+  const float conv_cos = (with_q || use == JR_ORTH) ? CONV_COS : conv_sigma;
   const float skip_thr = SKIP_FRACTION * conv_cos;
   (void)sigma_only;
   ctx->ref_skip_thr = skip_thr;
@@ -754,17 +799,19 @@ int fetch_norms(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std:
 // b2^2 / |T[:, i]|^2 so that sqrt(b2 / q2) is s_i like in the [A | I] formulation.
 //   A0: dense [B][L][M] copy of the input rows;  T: dense [B][L][Lp] (left on the device).
 int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0, float* T, std::vector<double>& b2,
-                  std::vector<double>& q2, std::vector<unsigned char>* reliable = nullptr) {
+                  std::vector<double>& q2, std::vector<unsigned char>* reliable = nullptr,
+                  std::vector<double>* t2_raw = nullptr) {
+  // all planes' products in one launch (grid.z = plane)
   hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, 0, w.b2, w.q2);
-  for (int z = 0; z < p.B; ++z)
-    WM_TRY(sgemm(ctx, false, true, p.L, p.Lp, p.M, 1.0f, A0 + (size_t)z * p.L * p.M, p.M, w.aug + (size_t)z * p.aug_ps, p.ld,
-                 0.0f, T + (size_t)z * p.L * p.Lp, p.Lp));
+  WM_TRY(sgemm_b(ctx, false, true, p.L, p.Lp, p.M, 1.0f, A0, p.M, (size_t)p.L * p.M, w.aug, p.ld, p.aug_ps, 0.0f, T, p.Lp,
+                 (size_t)p.L * p.Lp, p.B));
   hipLaunchKernelGGL(k_rf_colnorms, dim3((p.Lp + 63) / 64, p.B), dim3(256), 0, ctx->stream, T, (size_t)p.L * p.Lp, p.L, p.Lp, w.q2);
   WM_HIP(hipGetLastError());
   b2.resize((size_t)p.B * p.Lp); q2.resize((size_t)p.B * p.Lp);
   WM_HIP(hipMemcpyAsync(b2.data(), w.b2, b2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipMemcpyAsync(q2.data(), w.q2, q2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
+  if (t2_raw) *t2_raw = q2;                            // |T[:, i]|^2 as measured, before q2 becomes the sigma factor
   // |T[:, i]| = |b_i| s_i must agree with |b_i|^2 up to the rotations' scale drift (a few 1e-4).
   // A row that fails this is rounding residue of a rank-deficient plane - its direction is noise,
   // A0 b_i^T measures nothing - and keeps its own (tiny) norm as singular value.
@@ -836,13 +883,306 @@ inline size_t span_of(int n_planes, int H, int W, int row_stride, size_t plane_s
   return (size_t)(n_planes - 1) * plane_stride + (size_t)(H - 1) * row_stride + (size_t)W;
 }
 
+
+// ---------------------------------------------------------------------------
+// cores: every plane-sized array is DEVICE memory; the small per-plane vectors (singular values, the
+// embed coefficients) cross to the host once per call, where they are sorted / classified
+// ---------------------------------------------------------------------------
+struct RefSpectrum {                     // host-side result of one batched Jacobi + T = A0 B^T pass
+  std::vector<double> b2, q2, t2;        // [B][Lp] |b_i|^2, the factor that turns it into sigma_i^2, |T[:, i]|^2
+  std::vector<unsigned char> reliable;   // [B][Lp] u_i = T[:, i] / (|b_i| s_i) is a usable left vector
+};
+
+// planes (uint8, device) -> rotated rows B in w.aug, A0 copy in d_a0 [B][L][M], T = A0 B^T in d_t [B][L][Lp],
+// spectrum on the host
+int ref_decompose(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t* d_planes, size_t row_stride,
+                  size_t plane_stride, float* d_a0, float* d_t, JacobiUse use, RefSpectrum& sp) {
+  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, d_planes, row_stride,
+                     plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
+  WM_TRY(copy_a_part(ctx, p, w, d_a0));
+  int sweeps = 0;
+  WM_TRY(jacobi_rows(ctx, p, w, use, &sweeps));
+  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
+  WM_TRY(fetch_norms_t(ctx, p, w, d_a0, d_t, sp.b2, sp.q2, &sp.reliable, &sp.t2));
+  return WM_OK;
+}
+
+// singular values of n planes on the device -> host sig [B][L]
+int ref_sigma_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t* d_planes, size_t row_stride,
+                   size_t plane_stride, float* d_a0, float* d_t, float* sig_host) {
+  RefSpectrum sp;
+  WM_TRY(ref_decompose(ctx, p, w, d_planes, row_stride, plane_stride, d_a0, d_t, JR_SIGMA, sp));
+  std::vector<int> order; std::vector<float> sig;
+  for (int z = 0; z < p.B; ++z) {
+    sort_sigma(p, &sp.b2[(size_t)z * p.Lp], &sp.q2[(size_t)z * p.Lp], order, sig);
+    memcpy(sig_host + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
+  }
+  return WM_OK;
+}
+
+// Null-space completion of ONE rank-deficient plane z.  The reference injects alpha*Sw[k]
+// for EVERY k < K (single:174-176): where the plane has no k-th singular direction LAPACK supplies some
+// orthonormal completion of the null spaces.  Here: n deterministic pseudo-random vectors per side are
+// projected off the valid singular vectors (twice), orthogonalised by the same block Jacobi, normalised,
+// and  sum_k w_k u_k v_k^T  is added to Yw.  With every u and every v orthonormal,
+// svd(Yw) = {s_i + w_i} U {w_k}: the reference's invariant  S(Cw)[:K] = Sc[:K] + alpha Sw[:K].
+//   valid [Lp]: 1 for rows of B that are singular directions; wk [n]: the energies of the missing ranks;
+//   tnorm2 [Lp]: |T[:, i]|^2.  d_yw: this plane's Yw in A layout [L][M].
+int ref_complete_plane(wm_ctx* ctx, const RefPlan& p, const RefWs& w, int z, const std::vector<unsigned char>& valid,
+                       const double* b2, const double* tnorm2, const std::vector<float>& wk, const float* d_t_z,
+                       float* d_yw_z) {
+  const int n = (int)wk.size();
+  if (n == 0) return WM_OK;
+  const float* Bz = w.aug + (size_t)z * p.aug_ps;
+  // side 0: right vectors (length M, against the rows of B); side 1: left vectors (length L, against the columns of T)
+  const RefPlan pv = make_plan(n, p.M), pu = make_plan(n, p.L);
+  RefWs wv;
+  // second workspace, planned for the larger of the two Jacobi runs (n x M; the n x L one has the same
+  // block count and fewer columns and reuses its arrays).  tmp1: Zv [n][M] | Zu [n][L] | C [n][Lp] | coefficients [Lp]
+  WM_TRY(plan_workspace(ctx, pv, wv, (size_t)n * (p.M + p.L + p.Lp) + p.Lp + 64, 16, 1));
+  float* Zv = wv.tmp1; float* Zu = Zv + (size_t)n * p.M; float* C = Zu + (size_t)n * p.L; float* coef = C + (size_t)n * p.Lp;
+  std::vector<float> gv(p.Lp), gu(p.Lp);
+  for (int i = 0; i < p.Lp; ++i) {
+    gv[i] = (valid[i] && b2[i] > 0.0) ? (float)(1.0 / b2[i]) : 0.0f;
+    gu[i] = (valid[i] && tnorm2[i] > 0.0) ? (float)(1.0 / tnorm2[i]) : 0.0f;
+  }
+  hipLaunchKernelGGL(k_rf_pattern, dim3(8, n), dim3(256), 0, ctx->stream, Zv, n, p.M, 0x1234567u);
+  hipLaunchKernelGGL(k_rf_pattern, dim3(8, n), dim3(256), 0, ctx->stream, Zu, n, p.L, 0x7654321u);
+  for (int side = 0; side < 2; ++side) {
+    float* Z = side == 0 ? Zv : Zu;
+    const int len = side == 0 ? p.M : p.L;
+    WM_HIP(hipMemcpyAsync(coef, (side == 0 ? gv : gu).data(), (size_t)p.Lp * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (int pass = 0; pass < 2; ++pass) {          // project twice: classical Gram-Schmidt loses digits once
+      if (side == 0) WM_TRY(sgemm(ctx, false, true, n, p.Lp, p.M, 1.0f, Z, p.M, Bz, p.ld, 0.0f, C, p.Lp));       // Z B^T
+      else WM_TRY(sgemm(ctx, false, false, n, p.Lp, p.L, 1.0f, Z, p.L, d_t_z, p.Lp, 0.0f, C, p.Lp));              // Z T
+      hipLaunchKernelGGL(k_rf_scale_cols_b, dim3(8, n, 1), dim3(256), 0, ctx->stream, C, (size_t)0, C, (size_t)0, p.Lp, coef, (size_t)0);
+      if (side == 0) WM_TRY(sgemm(ctx, false, false, n, p.M, p.Lp, -1.0f, C, p.Lp, Bz, p.ld, 1.0f, Z, p.M));      // Z -= C B
+      else WM_TRY(sgemm(ctx, false, true, n, p.L, p.Lp, -1.0f, C, p.Lp, d_t_z, p.Lp, 1.0f, Z, p.L));              // Z -= C T^T
+    }
+    WM_HIP(hipStreamSynchronize(ctx->stream));      // gv / gu are locals reused by the next side
+  }
+  // orthogonalise the rows of each Z with the block Jacobi (row span is preserved), then  Yw += Zu^T diag(d) Zv
+  std::vector<double> nv, nu, dummy;
+  std::vector<int> ordv, ordu;
+  float* aug2 = wv.aug;
+  auto orth = [&](const RefPlan& pp, float* Z, int len, std::vector<double>& norms2, std::vector<int>& ord) -> int {
+    RefWs ww = wv;
+    WM_TRY(get_pairs(ctx, pp, &ww.pairs));
+    hipLaunchKernelGGL((k_rf_load<float>), dim3(8, pp.Lp, 1), dim3(256), 0, ctx->stream, Z, (size_t)len, (size_t)0, 0,
+                       aug2, pp.aug_ps, pp.ld, pp.L, pp.Lp, pp.M);
+    int sweeps = 0;
+    WM_TRY(jacobi_rows(ctx, pp, ww, JR_ORTH, &sweeps));
+    if (sweeps < 0) return set_err(WM_ERR_NOCONV, "null-space completion did not converge");
+    WM_TRY(fetch_norms(ctx, pp, ww, false, norms2, dummy));
+    ord.resize(pp.Lp);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return norms2[a] > norms2[b]; });
+    // gather the n largest rows back into Z, normalised
+    std::vector<float> sc(n);
+    for (int k = 0; k < n; ++k) sc[k] = norms2[ord[k]] > 0.0 ? (float)(1.0 / sqrt(norms2[ord[k]])) : 0.0f;
+    WM_HIP(hipMemcpyAsync(ww.order, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemcpyAsync(ww.scale, sc.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, n), dim3(256), 0, ctx->stream, aug2, pp.ld, len, ww.order, ww.scale, Z, len);
+    WM_HIP(hipStreamSynchronize(ctx->stream));       // ord / sc are locals
+    return WM_OK;
+  };
+  // the workspace arrays of wv were sized for pv = (n, M); pu = (n, L) has the same row count and fewer columns
+  WM_TRY(orth(pv, Zv, p.M, nv, ordv));
+  WM_TRY(orth(pu, Zu, p.L, nu, ordu));
+  // Zu rows scaled by the energies, then Yw += Zu^T Zv   ([L x n] [n x M])
+  WM_HIP(hipMemcpyAsync(coef, wk.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, n, 1), dim3(256), 0, ctx->stream, Zu, (size_t)0, p.L, p.L, coef);
+  WM_TRY(sgemm(ctx, true, false, p.L, p.M, n, 1.0f, Zu, p.L, Zv, p.M, 1.0f, d_yw_z, p.M));
+  WM_HIP(hipStreamSynchronize(ctx->stream));         // wk is the caller's, coef reused
+  return WM_OK;
+}
+
+// embed of p.B planes on the device.  d_in / d_out: uint8 planes (same strides; may alias);
+// d_ywout: optional dense float [B][H][W]; sigma_w: HOST [B or 1][L]; sigma_c: HOST [B][L] out.
+// d_yw [B][L][M] and d_t [B][L][Lp] are workspace.
+int ref_embed_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t* d_in, uint8_t* d_out, float* d_ywout,
+                   size_t row_stride, size_t plane_stride, float* d_yw, float* d_t, const float* sigma_w,
+                   size_t sigma_w_plane_stride, float* sigma_c, float alpha, int K) {
+  const size_t yw_ps = (size_t)p.L * p.M;
+  RefSpectrum sp;
+  // Yw starts as A itself (exactly the pixels): ref_decompose leaves that copy in d_yw
+  WM_TRY(ref_decompose(ctx, p, w, d_in, row_stride, plane_stride, d_yw, d_t, JR_EMBED, sp));
+  // U diag(alpha Sw) V^T = T diag(e) B  with  e_i = alpha * sw[rank(i)] / (s_i |b_i|^2), rank < K
+  // (u_i = T[:, i] / (|b_i| s_i), v_i^T = b_i / |b_i|;  S_[:K] = Sc[:K] + alpha*Sw[:K]).
+  std::vector<float> d((size_t)p.B * p.Lp, 0.0f);
+  std::vector<int> order; std::vector<float> sig;
+  struct Todo { int z; std::vector<unsigned char> valid; std::vector<float> wk; std::vector<double> t2; };
+  std::vector<Todo> todo;
+  for (int z = 0; z < p.B; ++z) {
+    const double* pb = &sp.b2[(size_t)z * p.Lp]; const double* pq = &sp.q2[(size_t)z * p.Lp];
+    sort_sigma(p, pb, pq, order, sig);
+    memcpy(sigma_c + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
+    const float* sw = sigma_w + (size_t)z * sigma_w_plane_stride;
+    const double s1 = sig.empty() ? 0.0 : (double)sig[0];
+    Todo td; td.z = z; td.valid.assign(p.Lp, 0);
+    td.t2.assign(sp.t2.begin() + (size_t)z * p.Lp, sp.t2.begin() + (size_t)(z + 1) * p.Lp);
+    for (int i = 0; i < p.Lp; ++i) {
+      // a singular direction: consistent T column, above the null ratio (sigma_i^2 = b2 / q2)
+      const double s2 = pb[i] / (pq[i] > 0 ? pq[i] : 1.0);
+      td.valid[i] = (sp.reliable[(size_t)z * p.Lp + i] && sqrt(s2) > NULL_RATIO * s1 && pb[i] > 0.0) ? 1 : 0;
+    }
+    for (int k = 0; k < std::min(K, p.L); ++k) {
+      const int i = order[k];
+      const double si = (double)sig[k];
+      if (td.valid[i]) d[(size_t)z * p.Lp + i] = (float)((double)alpha * (double)sw[k] / (si * pb[i]));
+      else td.wk.push_back(alpha * sw[k]);           // rank k has no singular direction in this plane: completed below
+    }
+    if (!td.wk.empty()) todo.push_back(std::move(td));
+  }
+  WM_HIP(hipMemcpyAsync(w.dvec, d.data(), d.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  // completion reads the unscaled rows of B: it runs before the rows are scaled in place
+  if (!todo.empty()) {
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    for (const Todo& td : todo)
+      WM_TRY(ref_complete_plane(ctx, p, w, td.z, td.valid, &sp.b2[(size_t)td.z * p.Lp], td.t2.data(), td.wk,
+                                d_t + (size_t)td.z * p.L * p.Lp, d_yw + (size_t)td.z * yw_ps));
+  }
+  hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, w.dvec);
+  // Yw += T (diag(e) B):   [L x Lp] times [Lp x M], all planes in one launch
+  WM_TRY(sgemm_b(ctx, false, false, p.L, p.M, p.Lp, 1.0f, d_t, p.Lp, (size_t)p.L * p.Lp, w.aug, p.ld, p.aug_ps, 1.0f,
+                 d_yw, p.M, yw_ps, p.B));
+  hipLaunchKernelGGL(k_rf_quant, dim3(8, p.H, p.B), dim3(256), 0, ctx->stream, d_yw, yw_ps, p.M, p.transpose ? 1 : 0,
+                     d_out, row_stride, plane_stride, d_ywout, p.H, p.W);
+  WM_HIP(hipGetLastError());
+  WM_HIP(hipStreamSynchronize(ctx->stream));         // d is a local
+  return WM_OK;
+}
+
+// extract of B planes: sigma(stego) -> Sw_hat -> Uw[:L,:L] diag(Sw_hat) Vwt[:L,:L], zero-padded -> idct2.
+// d_uw [H][L] and d_vwt [L][W] are the meta factors on the device (leading dimensions L and W);
+// sigma_c HOST [B][L]; d_out dense float [B][H][W].  ws: tmp1 = Uw diag(sh) [B][L][L], tmp2 tail = GEMM intermediate [B][H][W].
+int ref_extract_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* s_cw, const float* sigma_c,
+                     const float* d_uw, const float* d_vwt, float* d_us, float* d_mid, float* d_out, float alpha, int K) {
+  const int L = p.L, H = p.H, W = p.W;
+  const float a = fmaxf(alpha, 1e-8f);
+  std::vector<float> sh((size_t)p.B * p.Lp, 0.0f);
+  for (int z = 0; z < p.B; ++z)
+    for (int i = 0; i < K; ++i)
+      sh[(size_t)z * p.Lp + i] = (s_cw[(size_t)z * L + i] - sigma_c[(size_t)z * L + i]) / a;                  // single:212-213
+  WM_HIP(hipMemcpyAsync(w.dvec, sh.data(), sh.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  float *dH, *dW;
+  WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
+  // Uw[:L,:L] * sh (column scaling) per plane: the first L rows of Uw (leading dimension L)
+  hipLaunchKernelGGL(k_rf_scale_cols_b, dim3(8, L, p.B), dim3(256), 0, ctx->stream, d_uw, (size_t)0, d_us, (size_t)L * L, L,
+                     w.dvec, (size_t)p.Lp);
+  WM_HIP(hipMemsetAsync(d_out, 0, (size_t)p.B * H * W * 4, ctx->stream));                                     // single:215
+  WM_TRY(sgemm_b(ctx, false, false, L, L, L, 1.0f, d_us, L, (size_t)L * L, d_vwt, W, 0, 0.0f, d_out, W, (size_t)H * W, p.B));  // single:214, 216-217 (Vwt[:L,:L]: ld W)
+  WM_TRY(sgemm_b(ctx, true, false, H, W, H, 1.0f, dH, H, 0, d_out, W, (size_t)H * W, 0.0f, d_mid, W, (size_t)H * W, p.B));   // idct2: D_H^T X
+  WM_TRY(sgemm_b(ctx, false, false, H, W, W, 1.0f, d_mid, W, (size_t)H * W, dW, W, 0, 0.0f, d_out, W, (size_t)H * W, p.B));  //        ... D_W   single:218
+  WM_HIP(hipStreamSynchronize(ctx->stream));         // sh is a local
+  return WM_OK;
+}
+
+double nc_score(const float* sw, const float* scw, const float* sc, int L, float alpha) {
+  // _nc(Sw[:L], (S_cw - Sc) / max(alpha, 1e-8))     single:297-301, 284-289
+  const float a = fmaxf(alpha, 1e-8f);
+  std::vector<double> x(L), y(L);
+  double sa = 0, sb = 0;
+  for (int i = 0; i < L; ++i) { x[i] = sw[i]; y[i] = (double)((scw[i] - sc[i]) / a); sa += x[i]; sb += y[i]; }
+  sa /= L; sb /= L;
+  double cov = 0, va = 0, vb = 0;
+  for (int i = 0; i < L; ++i) { const double dx = x[i] - sa, dy = y[i] - sb; cov += dx * dy; va += dx * dx; vb += dy * dy; }
+  return cov / (sqrt(va) * sqrt(vb) + 1e-8);
+}
+
+// small device -> host copy of a float vector (meta-sized arrays of the *_dev entry points)
+int fetch_f32(wm_ctx* ctx, const float* d, size_t n, std::vector<float>& h) {
+  h.resize(n);
+  if (n) {
+    WM_HIP(hipMemcpyAsync(h.data(), d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return WM_OK;
+}
+
 }  // namespace
 
 // ===========================================================================
-// C ABI (host-pointer entry points; see include/wmhip.h)
+// C ABI (see include/wmhip.h)
 // ===========================================================================
 extern "C" {
 
+// ---- device-pointer entry points: frames stay resident -------------------------------------
+int wm_ref_sigma_planes_u8_dev(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H, int W,
+                               int row_stride, size_t plane_stride) {
+  WM_TRY(check_ref_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
+  if (!sigma) return set_err(WM_ERR_BADARG, "sigma is NULL");
+  const RefPlan p = make_plan(H, W, n_planes);
+  RefWs w;
+  WM_TRY(plan_workspace(ctx, p, w, 16, (size_t)n_planes * p.L * (p.M + p.Lp)));   // tmp2: A0 [B][L][M] | T [B][L][Lp]
+  std::vector<float> sig((size_t)n_planes * p.L);
+  WM_TRY(ref_sigma_core(ctx, p, w, planes, (size_t)row_stride, plane_stride, w.tmp2, w.tmp2 + (size_t)n_planes * p.L * p.M,
+                        sig.data()));
+  WM_HIP(hipMemcpyAsync(sigma, sig.data(), sig.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+int wm_ref_embed_planes_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,
+                               float* yw, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                               size_t sigma_w_plane_stride, float alpha, int K) {
+  WM_TRY(check_ref_args(ctx, host, n_planes, H, W, row_stride, plane_stride));
+  if (!sigma_w || !stego || !sigma_c) return set_err(WM_ERR_BADARG, "NULL argument");
+  const RefPlan p = make_plan(H, W, n_planes);
+  if (K < 0 || K > p.L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
+  RefWs w;
+  WM_TRY(plan_workspace(ctx, p, w, 16, (size_t)n_planes * p.L * (p.M + p.Lp)));   // tmp2: Yw [B][L][M] | T [B][L][Lp]
+  std::vector<float> sw, sc((size_t)n_planes * p.L);
+  WM_TRY(fetch_f32(ctx, sigma_w, sigma_w_plane_stride ? (size_t)(n_planes - 1) * sigma_w_plane_stride + p.L : (size_t)p.L, sw));
+  // pixels the tiles do not cover do not exist in this mode: every pixel of stego is written by the quantiser
+  WM_TRY(ref_embed_core(ctx, p, w, host, stego, yw, (size_t)row_stride, plane_stride, w.tmp2,
+                        w.tmp2 + (size_t)n_planes * p.L * p.M, sw.data(), sigma_w_plane_stride, sc.data(), alpha, K));
+  WM_HIP(hipMemcpyAsync(sigma_c, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+int wm_ref_extract_planes_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                                 const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                                 size_t plane_stride, float alpha, int K) {
+  WM_TRY(check_ref_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!sigma_c || !Uw || !Vwt || !out) return set_err(WM_ERR_BADARG, "NULL argument");
+  const RefPlan p = make_plan(H, W, n_planes);
+  const int L = p.L;
+  if (K < 0 || K > L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
+  RefWs w;
+  // tmp1: Uw diag(sh) [B][L][L];  tmp2: A0 [B][L][M] | T [B][L][Lp], reused afterwards as the GEMM intermediate [B][H][W]
+  WM_TRY(plan_workspace(ctx, p, w, (size_t)n_planes * L * L + 16,
+                        std::max((size_t)n_planes * p.L * (p.M + p.Lp), (size_t)n_planes * H * W)));
+  std::vector<float> s_cw((size_t)n_planes * L), sc;
+  WM_TRY(ref_sigma_core(ctx, p, w, stego, (size_t)row_stride, plane_stride, w.tmp2, w.tmp2 + (size_t)n_planes * p.L * p.M,
+                        s_cw.data()));                                                                   // single:205
+  WM_TRY(fetch_f32(ctx, sigma_c, (size_t)n_planes * L, sc));
+  return ref_extract_core(ctx, p, w, s_cw.data(), sc.data(), Uw, Vwt, w.tmp1, w.tmp2, out, alpha, K);
+}
+
+int wm_ref_detect_planes_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
+                                double* scores, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                                float alpha) {
+  WM_TRY(check_ref_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!sigma_c || !sigma_w || !scores) return set_err(WM_ERR_BADARG, "NULL argument");
+  const RefPlan p = make_plan(H, W, n_planes);
+  RefWs w;
+  WM_TRY(plan_workspace(ctx, p, w, 16, (size_t)n_planes * p.L * (p.M + p.Lp)));
+  std::vector<float> s_cw((size_t)n_planes * p.L), sc, sw;
+  WM_TRY(ref_sigma_core(ctx, p, w, stego, (size_t)row_stride, plane_stride, w.tmp2, w.tmp2 + (size_t)n_planes * p.L * p.M,
+                        s_cw.data()));
+  WM_TRY(fetch_f32(ctx, sigma_c, (size_t)n_planes * p.L, sc));
+  WM_TRY(fetch_f32(ctx, sigma_w, (size_t)p.L, sw));
+  std::vector<double> sco(n_planes);
+  for (int z = 0; z < n_planes; ++z)
+    sco[z] = nc_score(sw.data(), &s_cw[(size_t)z * p.L], &sc[(size_t)z * p.L], p.L, alpha);
+  WM_HIP(hipMemcpyAsync(scores, sco.data(), sco.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+// ---- host-pointer entry points ------------------------------------------------------------------
 int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H, int W,
                            int row_stride, size_t plane_stride) {
   WM_TRY(check_ref_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
@@ -852,25 +1192,9 @@ int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int
   const size_t n_in = span_of(n_planes, H, W, row_stride, plane_stride);
   // tmp1: uint8 input span; tmp2: A0 [B][L][M] | T [B][L][Lp]
   WM_TRY(plan_workspace(ctx, p, w, (n_in + 3) / 4 + 4, (size_t)n_planes * p.L * (p.M + p.Lp)));
-  WM_TRY(upload_pairs(ctx, p, w));
   uint8_t* d_in = (uint8_t*)w.tmp1;
-  float* d_a0 = w.tmp2;
-  float* d_t = w.tmp2 + (size_t)n_planes * p.L * p.M;
   WM_HIP(hipMemcpyAsync(d_in, planes, n_in, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
-                     plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
-  WM_TRY(copy_a_part(ctx, p, w, d_a0));
-  int sweeps = 0;
-  WM_TRY(jacobi_rows(ctx, p, w, JR_SIGMA, &sweeps));
-  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
-  std::vector<double> b2, q2;
-  WM_TRY(fetch_norms_t(ctx, p, w, d_a0, d_t, b2, q2));
-  std::vector<int> order; std::vector<float> sig;
-  for (int z = 0; z < n_planes; ++z) {
-    sort_sigma(p, &b2[(size_t)z * p.Lp], &q2[(size_t)z * p.Lp], order, sig);
-    memcpy(sigma + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
-  }
-  return WM_OK;
+  return ref_sigma_core(ctx, p, w, d_in, (size_t)row_stride, plane_stride, w.tmp2, w.tmp2 + (size_t)n_planes * p.L * p.M, sigma);
 }
 
 int wm_ref_sigma_u8(wm_ctx* ctx, const uint8_t* plane, float* sigma, int H, int W, int row_stride) {
@@ -891,54 +1215,15 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
   // tmp1: uint8 input + output spans (+ dense float Yw for the caller);
   // tmp2: Yw in A layout [B][L][M] (starts as A0, the pixels) | T [B][L][Lp]
   WM_TRY(plan_workspace(ctx, p, w, (2 * n_in16) / 4 + 8 + yw_elems, (size_t)n_planes * p.L * (p.M + p.Lp)));
-  WM_TRY(upload_pairs(ctx, p, w));
   uint8_t* d_in = (uint8_t*)w.tmp1;
   uint8_t* d_out = d_in + n_in16;
   float* d_ywout = yw ? (float*)(d_out + n_in16) : nullptr;
-  float* d_yw = w.tmp2;
-  const size_t yw_ps = (size_t)p.L * p.M;
   WM_HIP(hipMemcpyAsync(d_in, host, n_in, hipMemcpyHostToDevice, ctx->stream));
+  // bytes between rows / planes that belong to the caller's stego buffer are carried through
   if (stego != host) WM_HIP(hipMemcpyAsync(d_out, stego, n_in, hipMemcpyHostToDevice, ctx->stream));
   else WM_HIP(hipMemcpyAsync(d_out, d_in, n_in, hipMemcpyDeviceToDevice, ctx->stream));
-  hipLaunchKernelGGL((k_rf_load<uint8_t>), dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, d_in, (size_t)row_stride,
-                     plane_stride, p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
-  // Yw starts as A itself (exactly the pixels): copy the first L rows of every B part before rotating
-  WM_TRY(copy_a_part(ctx, p, w, d_yw));
-  float* d_t = w.tmp2 + (size_t)n_planes * yw_ps;
-  int sweeps = 0;
-  WM_TRY(jacobi_rows(ctx, p, w, JR_EMBED, &sweeps));
-  if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
-  std::vector<double> b2, q2;
-  std::vector<unsigned char> reliable;
-  WM_TRY(fetch_norms_t(ctx, p, w, d_yw, d_t, b2, q2, &reliable));
-  // U diag(alpha Sw) V^T = T diag(e) B  with  e_i = alpha * sw[rank(i)] / (s_i |b_i|^2), rank < K
-  // (u_i = T[:, i] / (|b_i| s_i), v_i^T = b_i / |b_i|;  S_[:K] = Sc[:K] + alpha*Sw[:K]).
-  // Directions below NULL_RATIO * s_1 carry rounding noise instead of singular vectors: nothing is
-  // injected there (DESIGN.md 9, rank-deficient planes).
-  std::vector<float> d((size_t)n_planes * p.Lp, 0.0f);
-  std::vector<int> order; std::vector<float> sig;
-  for (int z = 0; z < n_planes; ++z) {
-    const double* pb = &b2[(size_t)z * p.Lp]; const double* pq = &q2[(size_t)z * p.Lp];
-    sort_sigma(p, pb, pq, order, sig);
-    memcpy(sigma_c + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
-    const float* sw = sigma_w + (size_t)z * sigma_w_plane_stride;
-    const double s1 = sig.empty() ? 0.0 : (double)sig[0];
-    for (int k = 0; k < std::min(K, p.L); ++k) {
-      const int i = order[k];
-      const double si = (double)sig[k];
-      d[(size_t)z * p.Lp + i] = (reliable[(size_t)z * p.Lp + i] && si > NULL_RATIO * s1 && pb[i] > 0.0)
-                                    ? (float)((double)alpha * (double)sw[k] / (si * pb[i])) : 0.0f;
-    }
-  }
-  WM_HIP(hipMemcpyAsync(w.dvec, d.data(), d.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, w.dvec);
-  // Yw += T (diag(e) B):   [L x Lp] times [Lp x M]
-  for (int z = 0; z < n_planes; ++z)
-    WM_TRY(sgemm(ctx, false, false, p.L, p.M, p.Lp, 1.0f, d_t + (size_t)z * p.L * p.Lp, p.Lp,
-                 w.aug + (size_t)z * p.aug_ps, p.ld, 1.0f, d_yw + (size_t)z * yw_ps, p.M));
-  hipLaunchKernelGGL(k_rf_quant, dim3(8, H, p.B), dim3(256), 0, ctx->stream, d_yw, yw_ps, p.M, p.transpose ? 1 : 0,
-                     d_out, (size_t)row_stride, plane_stride, d_ywout, H, W);
-  WM_HIP(hipGetLastError());
+  WM_TRY(ref_embed_core(ctx, p, w, d_in, d_out, d_ywout, (size_t)row_stride, plane_stride, w.tmp2,
+                        w.tmp2 + (size_t)n_planes * p.L * p.M, sigma_w, sigma_w_plane_stride, sigma_c, alpha, K));
   WM_HIP(hipMemcpyAsync(stego, d_out, n_in, hipMemcpyDeviceToHost, ctx->stream));
   if (yw) WM_HIP(hipMemcpyAsync(yw, d_ywout, yw_elems * 4, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -961,7 +1246,6 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
   const size_t n_in = (size_t)H * row_stride;
   // tmp1: input plane, then sorted factor for download; tmp2: DCT intermediate
   WM_TRY(plan_workspace(ctx, p, w, std::max(n_in, (size_t)p.M * p.L) + (size_t)H * W, (size_t)H * W));
-  WM_TRY(upload_pairs(ctx, p, w));
   float* d_in = w.tmp1;
   float* d_c = w.tmp1 + std::max(n_in, (size_t)p.M * p.L);     // H x W
   WM_HIP(hipMemcpyAsync(d_in, plane, n_in * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1012,45 +1296,35 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
   return WM_OK;
 }
 
-// extract: sigma(stego) -> Sw_hat -> Uw[:L,:L] diag(Sw_hat) Vwt[:L,:L], zero-padded -> idct2.
-// n_planes stego planes share one watermark decomposition (frames of a video): their SVDs
-// run batched, the three GEMMs per plane follow.
+
+// extract: n_planes stego planes share one watermark decomposition (frames of a video): their SVDs
+// run batched, the three GEMMs per plane run as one launch each (grid.z = plane).
 int wm_ref_extract_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
                              const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
                              size_t plane_stride, float alpha, int K) {
   WM_TRY(check_ref_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
   if (!sigma_c || !Uw || !Vwt || !out) return set_err(WM_ERR_BADARG, "NULL argument");
-  const int L = std::min(H, W);
+  const RefPlan p = make_plan(H, W, n_planes);
+  const int L = p.L;
   if (K < 0 || K > L) return set_err(WM_ERR_BADARG, "K must be in 0..min(H,W)");
-  std::vector<float> s_cw((size_t)n_planes * L);
-  WM_TRY(wm_ref_sigma_planes_u8(ctx, stego, s_cw.data(), n_planes, H, W, row_stride, plane_stride));   // single:205
-  const float a = fmaxf(alpha, 1e-8f);
-  const RefPlan p = make_plan(H, W);
   RefWs w;
-  // tmp1: Uw[:L,:L] | Vwt[:L,:L] | Uw*sh | padded product;  tmp2: GEMM intermediate
-  WM_TRY(plan_workspace(ctx, p, w, (size_t)L * L * 3 + (size_t)H * W, (size_t)H * W));
-  float* d_u = w.tmp1; float* d_v = d_u + (size_t)L * L; float* d_us = d_v + (size_t)L * L;
-  float* d_full = d_us + (size_t)L * L;
-  std::vector<float> vv((size_t)L * L);
-  for (int k = 0; k < L; ++k) memcpy(&vv[(size_t)k * L], &Vwt[(size_t)k * W], (size_t)L * 4);      // Vwt[:L,:L]
+  const size_t n_in = span_of(n_planes, H, W, row_stride, plane_stride);
+  const size_t n_in4 = (n_in + 3) / 4 + 4;
+  // tmp1: uint8 stego span | Uw[:L,:L] | Vwt [L][W] | Uw diag(sh) [B][L][L] | result [B][H][W]
+  // tmp2: A0 [B][L][M] | T [B][L][Lp], reused afterwards as the GEMM intermediate [B][H][W]
+  WM_TRY(plan_workspace(ctx, p, w, n_in4 + (size_t)L * L + (size_t)L * W + (size_t)n_planes * L * L + (size_t)n_planes * H * W,
+                        std::max((size_t)n_planes * p.L * (p.M + p.Lp), (size_t)n_planes * H * W)));
+  uint8_t* d_in = (uint8_t*)w.tmp1;
+  float* d_u = w.tmp1 + n_in4; float* d_v = d_u + (size_t)L * L; float* d_us = d_v + (size_t)L * W;
+  float* d_full = d_us + (size_t)n_planes * L * L;
+  WM_HIP(hipMemcpyAsync(d_in, stego, n_in, hipMemcpyHostToDevice, ctx->stream));
   WM_HIP(hipMemcpyAsync(d_u, Uw, (size_t)L * L * 4, hipMemcpyHostToDevice, ctx->stream));            // Uw[:L,:L] (H x L, rows < L)
-  WM_HIP(hipMemcpyAsync(d_v, vv.data(), vv.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  float *dH, *dW;
-  WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
-  std::vector<float> sh((size_t)p.Lp, 0.0f);
-  for (int z = 0; z < n_planes; ++z) {
-    std::fill(sh.begin(), sh.end(), 0.0f);
-    for (int i = 0; i < K; ++i) sh[i] = (s_cw[(size_t)z * L + i] - sigma_c[(size_t)z * L + i]) / a;   // single:212-213
-    WM_HIP(hipMemcpyAsync(w.dvec, sh.data(), (size_t)L * 4, hipMemcpyHostToDevice, ctx->stream));
-    WM_HIP(hipStreamSynchronize(ctx->stream));       // sh is reused by the next plane
-    // Uw[:L,:L] * sh (column scaling) == diag applied from the right:  (U diag(sh)) = (diag(sh) U^T)^T
-    hipLaunchKernelGGL(k_rf_scale_cols, dim3(8, L), dim3(256), 0, ctx->stream, d_u, d_us, L, w.dvec);
-    WM_HIP(hipMemsetAsync(d_full, 0, (size_t)H * W * 4, ctx->stream));                                // single:215
-    WM_TRY(sgemm(ctx, false, false, L, L, L, 1.0f, d_us, L, d_v, L, 0.0f, d_full, W));                // single:214, 216-217
-    WM_TRY(sgemm(ctx, true, false, H, W, H, 1.0f, dH, H, d_full, W, 0.0f, w.tmp2, W));                // idct2: D_H^T X
-    WM_TRY(sgemm(ctx, false, false, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_full, W));               //        ... D_W   single:218
-    WM_HIP(hipMemcpyAsync(out + (size_t)z * H * W, d_full, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
-  }
+  WM_HIP(hipMemcpyAsync(d_v, Vwt, (size_t)L * W * 4, hipMemcpyHostToDevice, ctx->stream));           // Vwt [L][W]; [:L,:L] = leading dimension W
+  std::vector<float> s_cw((size_t)n_planes * L);
+  WM_TRY(ref_sigma_core(ctx, p, w, d_in, (size_t)row_stride, plane_stride, w.tmp2, w.tmp2 + (size_t)n_planes * p.L * p.M,
+                        s_cw.data()));                                                                   // single:205
+  WM_TRY(ref_extract_core(ctx, p, w, s_cw.data(), sigma_c, d_u, d_v, d_us, w.tmp2, d_full, alpha, K));
+  WM_HIP(hipMemcpyAsync(out, d_full, (size_t)n_planes * H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
   return WM_OK;
 }
@@ -1068,7 +1342,6 @@ int wm_ref_last_sweeps(wm_ctx* ctx, int* sweeps_out) {
   return WM_OK;
 }
 
-// detect: _nc(Sw[:L], (S_cw - Sc) / max(alpha, 1e-8))     single:297-301, 284-289
 // detect over n_planes stego planes of one watermark (frames of a clip): batched SVDs, NC per plane
 int wm_ref_detect_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
                             double* scores, int n_planes, int H, int W, int row_stride, size_t plane_stride,
@@ -1078,17 +1351,8 @@ int wm_ref_detect_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigm
   const int L = std::min(H, W);
   std::vector<float> s_cw((size_t)n_planes * L);
   WM_TRY(wm_ref_sigma_planes_u8(ctx, stego, s_cw.data(), n_planes, H, W, row_stride, plane_stride));
-  const float a = fmaxf(alpha, 1e-8f);
-  std::vector<double> x(L), y(L);
-  for (int z = 0; z < n_planes; ++z) {
-    const float* scw = &s_cw[(size_t)z * L]; const float* sc = sigma_c + (size_t)z * L;
-    double sa = 0, sb = 0;
-    for (int i = 0; i < L; ++i) { x[i] = sigma_w[i]; y[i] = (double)((scw[i] - sc[i]) / a); sa += x[i]; sb += y[i]; }
-    sa /= L; sb /= L;
-    double cov = 0, va = 0, vb = 0;
-    for (int i = 0; i < L; ++i) { const double dx = x[i] - sa, dy = y[i] - sb; cov += dx * dy; va += dx * dx; vb += dy * dy; }
-    scores[z] = cov / (sqrt(va) * sqrt(vb) + 1e-8);
-  }
+  for (int z = 0; z < n_planes; ++z)
+    scores[z] = nc_score(sigma_w, &s_cw[(size_t)z * L], sigma_c + (size_t)z * L, L, alpha);
   return WM_OK;
 }
 

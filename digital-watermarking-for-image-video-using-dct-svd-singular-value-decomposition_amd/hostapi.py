@@ -76,6 +76,10 @@ SIGNATURES = {
     "wm_ref_last_sweeps": [_vp, C.POINTER(_i)],
     "wm_ref_embed_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_ref_sigma_planes_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
+    "wm_ref_embed_planes_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_ref_sigma_planes_u8_dev": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
+    "wm_ref_extract_planes_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f, _i],
+    "wm_ref_detect_planes_u8_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f],
     "wm_ref_svd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_extract_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f, _i],
@@ -267,6 +271,23 @@ class Context:
                             plane_stride, sigma_w_plane_stride, alpha):
         self._call("wm_detect_tiles_u8_dev", _vp(stego), _vp(sigma_c), _vp(sigma_w), _vp(scores),
                    n_planes, H, W, row_stride, plane_stride, sigma_w_plane_stride, alpha)
+
+    # full-frame mode, device-resident planes / factors (ints are device addresses)
+    def ref_embed_planes_u8_dev(self, host, sigma_w, stego, sigma_c, yw, n_planes, H, W, row_stride, plane_stride,
+                                sigma_w_plane_stride, alpha, K):
+        self._call("wm_ref_embed_planes_u8_dev", _vp(host), _vp(sigma_w), _vp(stego), _vp(sigma_c),
+                   _vp(yw) if yw else None, n_planes, H, W, row_stride, plane_stride, sigma_w_plane_stride, alpha, K)
+
+    def ref_sigma_planes_u8_dev(self, planes, sigma, n_planes, H, W, row_stride, plane_stride):
+        self._call("wm_ref_sigma_planes_u8_dev", _vp(planes), _vp(sigma), n_planes, H, W, row_stride, plane_stride)
+
+    def ref_extract_planes_u8_dev(self, stego, sigma_c, Uw, Vwt, out, n_planes, H, W, row_stride, plane_stride, alpha, K):
+        self._call("wm_ref_extract_planes_u8_dev", _vp(stego), _vp(sigma_c), _vp(Uw), _vp(Vwt), _vp(out), n_planes,
+                   H, W, row_stride, plane_stride, alpha, K)
+
+    def ref_detect_planes_u8_dev(self, stego, sigma_c, sigma_w, scores, n_planes, H, W, row_stride, plane_stride, alpha):
+        self._call("wm_ref_detect_planes_u8_dev", _vp(stego), _vp(sigma_c), _vp(sigma_w), _vp(scores), n_planes,
+                   H, W, row_stride, plane_stride, alpha)
 
     # ---- NumPy (host-buffer) entry points --------------------------------
     def embed_tiles(self, host: np.ndarray, sigma_w: np.ndarray, alpha: float, K: int = 8,

@@ -222,6 +222,24 @@ int wm_ref_extract_planes_u8(wm_ctx* ctx, const uint8_t* stego, const float* sig
                              const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
                              size_t plane_stride, float alpha, int K);
 
+/* Device-pointer forms of the batched full-frame entry points: the planes and the big factors
+ * (Uw [H][L], Vwt [L][W], out, yw) are DEVICE memory and never cross PCIe - the frames of a clip
+ * or the per-rank frame range of bench.py --mode fullframe stay resident.  The meta-sized vectors
+ * (sigma_w, sigma_c, sigma, scores) are device memory too; they are sorted / classified on the
+ * host inside the call (L floats per plane), so these calls synchronise the context's stream.
+ * Same statements of the reference as the host-pointer forms above. */
+int wm_ref_embed_planes_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego,
+                               float* sigma_c, float* yw, int n_planes, int H, int W, int row_stride,
+                               size_t plane_stride, size_t sigma_w_plane_stride, float alpha, int K);
+int wm_ref_sigma_planes_u8_dev(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H, int W,
+                               int row_stride, size_t plane_stride);
+int wm_ref_extract_planes_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
+                                 const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
+                                 size_t plane_stride, float alpha, int K);
+int wm_ref_detect_planes_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,
+                                double* scores, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                                float alpha);
+
 /* Diagnostics: outer Jacobi sweeps the last full-frame SVD on this context needed. */
 int wm_ref_last_sweeps(wm_ctx* ctx, int* sweeps_out);
 

@@ -149,13 +149,29 @@ def test_fullframe_rank_deficient_planes(gpu_ctx, idx):
     K = int(0.6 * min(H, W))
     st, sc, yw = gpu_ctx.ref_embed(x, Sw, 0.15, K, want_yw=True)
     assert np.isfinite(yw).all() and np.abs(sc - ref)[~null].max() < 2e-6 * ref[0] and sc[null].max() < 3e-5 * ref[0]
-    # oracle's own embed along the well-defined directions only (rank r): the GPU injects nothing below
-    # 1e-6 sigma_1, LAPACK's completion of the null space is arbitrary there
+    # Along the well-defined directions (rank r) the embed equals the float64 result; along the missing
+    # ones LAPACK's completion of the null spaces is arbitrary and so is ours - what the reference
+    # guarantees whatever the completion (single:174-176) is the singular-value invariant
+    #     svd(Cw)[:K] == Sc[:K] + alpha * Sw[:K]        for EVERY k < K,
+    # and that the added energy lives in the null spaces (orthonormal completion).
     r = int((ref > 1e-6 * ref[0]).sum())
     U, S, Vt = np.linalg.svd(x.astype(np.float64), full_matrices=False)
     kk = min(K, r)
     want = x.astype(np.float64) + (U[:, :kk] * (0.15 * Sw[:kk].astype(np.float64))) @ Vt[:kk]
-    assert np.abs(yw - want).max() < 5e-2
+    extra = yw.astype(np.float64) - want
+    s_yw = np.linalg.svd(yw.astype(np.float64), compute_uv=False)
+    target = ref.copy(); target[null] = 0.0
+    target[:K] += 0.15 * Sw[:K].astype(np.float64)
+    assert np.abs(s_yw[:K] - np.sort(target)[::-1][:K]).max() < 2e-5 * s_yw[0], np.abs(s_yw[:K] - np.sort(target)[::-1][:K]).max() / s_yw[0]
+    # what a reference-format extract computes from such a stego: (S_cw - Sc) / alpha == Sw on every index < K,
+    # the null ones included (they carried nothing before this round)
+    sw_hat = (s_yw[:K] - np.where(null, 0.0, ref)[:K]) / 0.15
+    assert np.abs(sw_hat - Sw[:K]).max() < 2e-4 * s_yw[0] / 0.15
+    if K > r:
+        assert np.abs(extra).max() > 1.0                                        # energy really was injected
+        assert np.abs(U[:, :r].T @ extra).max() < 5e-2 and np.abs(extra @ Vt[:r].T).max() < 5e-2
+    else:
+        assert np.abs(extra).max() < 5e-2
 
 
 @pytest.mark.parametrize("noise", [2.0, 0.5])
@@ -265,3 +281,49 @@ def test_fullframe_1080p_batch_of_three(gpu_ctx):
     sig = gpu_ctx.ref_sigma_planes(st)
     got = (sig[:, :K] - sc[:, :K]) / alpha
     assert np.corrcoef(got[0], Sw[:K])[0, 1] > 0.99
+
+
+def test_fullframe_device_pointer_entry_points_equal_the_host_forms(gpu_ctx):
+    """wm_ref_*_planes_u8_dev: planes, factors and the meta-sized vectors all in device memory (the frames of
+    a clip / a rank's frame range stay resident) - same numbers as the host-pointer forms, strided planes included."""
+    H, W, n, alpha, K = 96, 160, 3, 0.15, 57
+    L = min(H, W)
+    rng = np.random.default_rng(31)
+    rs, ps = W + 16, (W + 16) * H + 64                     # padded rows and planes
+    buf = rng.integers(0, 256, n * ps, dtype=np.uint8)
+    hosts = np.stack([buf[z * ps: z * ps + H * rs].reshape(H, rs)[:, :W] for z in range(n)])
+    wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+    U, S, Vt = gpu_ctx.ref_svd(wys, apply_dct=True)
+    st_h, sc_h, yw_h = gpu_ctx.ref_embed_planes(np.ascontiguousarray(hosts), S, alpha, K, want_yw=True)
+    c = gpu_ctx
+    d_in = c.malloc(buf.nbytes); c.h2d(d_in, buf)
+    d_out = c.malloc(buf.nbytes); c.h2d(d_out, buf)
+    d_sw = c.malloc(L * 4); c.h2d(d_sw, S)
+    d_sc = c.malloc(n * L * 4); d_yw = c.malloc(n * H * W * 4)
+    c.ref_embed_planes_u8_dev(d_in, d_sw, d_out, d_sc, d_yw, n, H, W, rs, ps, 0, alpha, K)
+    out = np.empty_like(buf); c.d2h(out, d_out)
+    sc_d = np.empty((n, L), np.float32); c.d2h(sc_d, d_sc)
+    yw_d = np.empty((n, H, W), np.float32); c.d2h(yw_d, d_yw)
+    st_d = np.stack([out[z * ps: z * ps + H * rs].reshape(H, rs)[:, :W] for z in range(n)])
+    assert np.array_equal(st_d, st_h) and np.array_equal(sc_d, sc_h) and np.array_equal(yw_d, yw_h)
+    pad = np.ones(buf.shape, bool)
+    for z in range(n):
+        pad[z * ps: z * ps + H * rs].reshape(H, rs)[:, :W] = False
+    assert np.array_equal(out[pad], buf[pad])              # bytes between rows / planes are the caller's
+    # sigma / extract / detect on the resident stego
+    d_sig = c.malloc(n * L * 4)
+    c.ref_sigma_planes_u8_dev(d_out, d_sig, n, H, W, rs, ps)
+    sig_d = np.empty((n, L), np.float32); c.d2h(sig_d, d_sig)
+    assert np.array_equal(sig_d, gpu_ctx.ref_sigma_planes(st_h))
+    d_u = c.malloc(U.nbytes); c.h2d(d_u, U); d_v = c.malloc(Vt.nbytes); c.h2d(d_v, Vt)
+    d_w = c.malloc(n * H * W * 4)
+    c.ref_extract_planes_u8_dev(d_out, d_sc, d_u, d_v, d_w, n, H, W, rs, ps, alpha, K)
+    w_d = np.empty((n, H, W), np.float32); c.d2h(w_d, d_w)
+    w_h = gpu_ctx.ref_extract_planes(st_h, sc_h, U, Vt, alpha, K)
+    assert np.array_equal(w_d, w_h)
+    d_s = c.malloc(n * 8)
+    c.ref_detect_planes_u8_dev(d_out, d_sc, d_sw, d_s, n, H, W, rs, ps, alpha)
+    s_d = np.empty(n, np.float64); c.d2h(s_d, d_s)
+    assert np.array_equal(s_d, gpu_ctx.ref_detect_planes(st_h, sc_h, S, alpha)) and s_d.min() > 0.9
+    for p in (d_in, d_out, d_sw, d_sc, d_yw, d_sig, d_u, d_v, d_w, d_s):
+        c.free(p)
