@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--mode", choices=("tile", "fullframe"), default="tile",
                     help="tile: the 8x8 hot path (contract default); fullframe: the reference's own "
                          "semantics (one dense SVD per plane), secondary workload")
+    ap.add_argument("--ff-frames", type=int, default=8, help="full-frame section: planes per rank per step")
+    ap.add_argument("--ff-height", type=int, default=1080)
+    ap.add_argument("--ff-width", type=int, default=1920)
+    ap.add_argument("--no-fullframe", action="store_true", help="skip the full-frame section of the default line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a 1-GPU box)")
@@ -87,65 +91,137 @@ def cpu_baseline(frames_u8, wys, alpha, stego_gpu, sc_gpu, wm_gpu):
              psnr_cpu=float(np.mean(psnr_cpu)), psnr_gpu=float(np.mean(psnr_gpu)))
 
 
-def main_fullframe(a):
-    """Secondary workload: reference semantics (tile=None) on BASELINE config 2's shape,
-    F planes batched through the host-pointer C ABI (PCIe copies of the planes included:
-    16.6 MB per 1080p embed+extract against tens of ms of SVD)."""
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        raise SystemExit("bench.py --mode fullframe is a single-GPU secondary workload (frames shard exactly like "
-                         "the tile mode's; the contract line is the default --mode tile)")
-    api = importlib.import_module(PKG + ".hostapi")
-    from oracle import wm_oracle as o
-    H = a.height if a.height != 2160 else 1080
-    W = a.width if a.width != 3840 else 1920
-    F = a.frames if a.frames != 32 else 8
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 runs at the vector rate)
+
+
+def fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup, cpu_sample=True):
+    """Reference semantics (tile=None): one dense SVD per plane (single:172-177, 205-218) on BASELINE config 2's
+    shape, F planes per rank per step, device-resident through the wm_ref_*_dev entry points.  Returns the
+    object that goes into the bench line (rank 0) - its own frames/s, MFMA roofline and CPU baseline."""
+    H = a.ff_height; W = a.ff_width; F = a.ff_frames
     L = min(H, W); K = max(8, int(0.6 * L)); alpha = a.alpha
-    ctx = api.Context(int(os.environ.get("LOCAL_RANK", "0")))
-    rng = np.random.default_rng(1234)
-    frames = rng.integers(0, 256, (F, H, W), dtype=np.uint8)
-    wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
-    Uw, Sw, Vwt = ctx.ref_svd(wys, apply_dct=True)          # once per watermark
+    g = torch.Generator(device=dev); g.manual_seed(4242 + rank)
+    frames = torch.randint(0, 256, (F, H, W), dtype=torch.uint8, device=dev, generator=g)
+    stego = torch.empty_like(frames)
+    sc = torch.empty((F, L), dtype=torch.float32, device=dev)
+    wm_out = torch.empty((F, H, W), dtype=torch.float32, device=dev)
+    Sw = torch.zeros((L,), dtype=torch.float32, device=dev)
+    Uw = torch.zeros((H, L), dtype=torch.float32, device=dev)
+    Vwt = torch.zeros((L, W), dtype=torch.float32, device=dev)
+    wys = None
+    if rank == 0:      # rank 0 owns the watermark: DCT + dense SVD once (single:173)
+        wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+        U_, S_, Vt_ = ctx.ref_svd(wys, apply_dct=True)
+        Sw.copy_(torch.from_numpy(S_)); Uw.copy_(torch.from_numpy(U_)); Vwt.copy_(torch.from_numpy(Vt_))
+    if world > 1:
+        for t_ in (Uw, Vwt):
+            dist.broadcast(t_, src=0)              # extract-side meta: once per watermark
 
     def step():
-        st, sc, _ = ctx.ref_embed_planes(frames, Sw, alpha, K)
+        if world > 1:
+            dist.broadcast(Sw, src=0)              # the path's exchange step (4.3 KB in this mode)
+        ctx.ref_embed_planes_u8_dev(frames.data_ptr(), Sw.data_ptr(), stego.data_ptr(), sc.data_ptr(), None,
+                                    F, H, W, W, H * W, 0, alpha, K)
         sweeps = ctx.ref_last_sweeps()
-        ctx.ref_extract_planes(st, sc, Uw, Vwt, alpha, K)
-        return st, sc, sweeps
+        ctx.ref_extract_planes_u8_dev(stego.data_ptr(), sc.data_ptr(), Uw.data_ptr(), Vwt.data_ptr(), wm_out.data_ptr(),
+                                      F, H, W, W, H * W, alpha, K)
+        return sweeps
 
-    for _ in range(max(1, min(a.warmup, 1))):
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
         step()
-    steps = max(1, min(a.steps, 5))
+    barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        st, sc, sweeps = step()
+        sweeps = step()
+    barrier()
     dt = time.perf_counter() - t0
+    # embed alone, for the roofline of the block-Jacobi step kernels
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    ctx.ref_embed_planes_u8_dev(frames.data_ptr(), Sw.data_ptr(), stego.data_ptr(), sc.data_ptr(), None,
+                                F, H, W, W, H * W, 0, alpha, K)
+    torch.cuda.synchronize(dev)
+    t_embed = time.perf_counter() - t1
+    sweeps_e = ctx.ref_last_sweeps()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return None
     Lp = (L + 63) // 64 * 64; M = max(H, W); nbk = Lp // 32
-    flops_sweep = (nbk - 1) * (nbk // 2) * (2.0 * 64 * 64 * M + 2.0 * 64 * 64 * M)   # gram + apply on the M columns (no [A | I] block)
-    t_embed0 = time.perf_counter(); ctx.ref_embed_planes(frames, Sw, alpha, K); t_embed = time.perf_counter() - t_embed0
-    achieved = flops_sweep * ctx.ref_last_sweeps() * F / t_embed / 1e12
-    t1 = time.perf_counter(); c0 = time.process_time()
-    e = o.embed_plane(frames[0].astype(np.float32), wys, alpha, 0.6, None)
-    o.extract_plane(e["stego"].astype(np.float32), e["Sc"], e["Uw"], e["Vwt"], alpha, 0.6, H, W, None)
-    wall = time.perf_counter() - t1
-    cores = max(1, round((time.process_time() - c0) / wall))
-    d = np.abs(st[0].astype(np.int16) - e["stego"].astype(np.int16))
-    out = {"metric": "frames/sec embed+extract, full-frame (reference semantics) Y plane", "value": F * steps / dt,
-           "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": dt / steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"full-frame (tile=None) embed+extract, {F} planes {W}x{H} uint8 Y batched, "
-                                  f"alpha={alpha}, K={K}; host-pointer API (PCIe copies included)",
-                      "frames_per_rank": F, "height": H, "width": W},
-           "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
-                        "traffic": None, "kernel": "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)",
-                        "note": f"{ctx.ref_last_sweeps()} sweeps; each step also moves 3 x planes x Lp x M x 4 B (gram read, apply read+write) "
-                                f"and waits ~35 us on the per-pair inner solve, float32 (MFMA f32 rate = VALU rate)"},
-           "cpu_baseline": {"value": 1.0 / wall, "unit": "frames/s", "cores": int(cores), "kind": "port",
-                            "sample": f"1 frame {W}x{H}: NumPy/LAPACK oracle embed (incl. its watermark SVD) + extract",
-                            "host_cpus": os.cpu_count()},
-           "parity": {"stego_max_lsb": int(d.max()), "stego_frac_diff": float((d != 0).mean()),
-                      "sigma_max_rel": float(np.max(np.abs(sc[0] - e["Sc"])) / e["Sc"][0])}}
-    print(json.dumps(out), flush=True)
+    flops_sweep = (nbk - 1) * (nbk // 2) * (2.0 * 64 * 64 * M + 2.0 * 64 * 64 * M)   # gram + apply GEMM tiles of one sweep
+    achieved = flops_sweep * sweeps_e * F / t_embed / 1e12
+    out = {"metric": "frames/sec embed+extract, full-frame (reference semantics) Y plane",
+           "value": world * F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "dtype": "f32",
+           "workload": f"full-frame (tile=None) embed+extract, {F} planes/rank/step of {W}x{H} uint8 Y, alpha={alpha}, K={K}, "
+                       f"device-resident (wm_ref_*_dev)",
+           "embed_ms": t_embed * 1e3, "embed_ms_per_plane": t_embed * 1e3 / F,
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)",
+                        "note": f"{sweeps_e} sweeps x {nbk - 1} steps; gram + apply flops only, over the whole embed call "
+                                f"(the per-pair inner solve and the finalisation GEMMs are in the time, not in the flops)"}}
+    if cpu_sample:
+        from oracle import wm_oracle as o
+        f0 = frames[0].cpu().numpy()
+        t2 = time.perf_counter(); c0 = time.process_time()
+        e = o.embed_plane(f0.astype(np.float32), wys, alpha, 0.6, None)
+        o.extract_plane(e["stego"].astype(np.float32), e["Sc"], e["Uw"], e["Vwt"], alpha, 0.6, H, W, None)
+        wall = time.perf_counter() - t2
+        cores = max(1, round((time.process_time() - c0) / wall))
+        st0 = stego[0].cpu().numpy(); sc0 = sc[0].cpu().numpy()
+        d = np.abs(st0.astype(np.int16) - e["stego"].astype(np.int16))
+        out["cpu_baseline"] = {"value": 1.0 / wall, "unit": "frames/s", "cores": int(cores), "kind": "port",
+                               "sample": f"1 frame {W}x{H}: NumPy/LAPACK oracle of single:172-177,205-218 - embed "
+                                         f"(incl. its watermark SVD) + extract", "host_cpus": os.cpu_count()}
+        out["parity"] = {"stego_max_lsb": int(d.max()), "stego_frac_diff": float((d != 0).mean()),
+                         "sigma_max_rel": float(np.max(np.abs(sc0 - e["Sc"])) / e["Sc"][0])}
+    return out
+
+
+def main_fullframe(a):
+    """--mode fullframe: the reference-semantics workload as the line's own metric (frames shard like tile mode)."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
+    api = importlib.import_module(PKG + ".hostapi")
+    ctx = api.Context(local_rank, stream=torch.cuda.current_stream(dev).cuda_stream)
+    steps = max(1, min(a.steps, 5)); warmup = max(1, min(a.warmup, 1))
+    r = fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup, cpu_sample=(world == 1 and a.cpu_frames > 0))
+    if rank == 0:
+        out = {"metric": r["metric"], "value": r["value"], "unit": "frames/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": r["workload"], "frames_per_rank": a.ff_frames, "height": a.ff_height,
+                          "width": a.ff_width, "parallelism": f"frames sharded over {world} rank(s)"},
+               "roofline": r["roofline"], "embed_ms_per_plane": r["embed_ms_per_plane"]}
+        for k in ("cpu_baseline", "parity"):
+            if k in r:
+                out[k] = r[k]
+        print(json.dumps(out), flush=True)
     ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def launch_ranks(a) -> int:
@@ -325,6 +401,11 @@ def main():
                                    wm_out[:n].cpu().numpy())
             out["cpu_baseline"] = cb
             out["parity"] = par
+        if world == 1 and not a.no_fullframe and (H, W) == (2160, 3840):
+            # after the timed tile-mode region (value / ms_per_step above are untouched): the reference's own
+            # full-frame semantics on BASELINE config 2's shape, with its own roofline and CPU baseline
+            out["fullframe"] = fullframe_section(a, torch, dist, api, dev, rank, world, ctx, 2, 1,
+                                                 cpu_sample=a.cpu_frames > 0)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

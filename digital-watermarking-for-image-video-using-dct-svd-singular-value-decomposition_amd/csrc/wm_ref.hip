@@ -236,8 +236,23 @@ __device__ __forceinline__ int rr_elem(const int pos, const int step) {
 // (bipartite schedule, 32 steps); the within-block pairs are covered once per
 // outer sweep by the full 63-step schedule (every block sits in exactly one
 // pair of the sweep's first step).
-constexpr int INNER_NT = 1024;                 // threads per workgroup: one 2x2 block of G per thread
+// Thread layout: thread (kr = t >> 5, k2 = t & 31) owns column pair k2 and the row pairs kr + KR i: with
+// INNER_NT = 512 threads two 2x2 blocks of G and four (row, column pair) items of R per step.
+// What bounds a step (measured, profiles/r02_fullframe_inner.md): in-kernel stamps give 1 716 cycles per
+// cross-only step for 1024 AND for 512 threads (2 540 with the full 63-step schedule, whose index arithmetic
+// branches) - a step is the LDS pipe's time, not the instruction count: every step reads and rewrites all of
+// G and R (19.5 k dword accesses; 8 192 of them ds_write_b32 at 64 B/clk/CU = 512 cycles, the reads 350) in
+// lock-step bursts between two barriers, plus the angle arithmetic's two v_rsq_f32 chains (~250 cycles)
+// that nothing else can run under.  256 threads (one wave per SIMD) lose the latency hiding (39.7 us per
+// solve against 30.1); 512 threads issue the per-pair angle and index arithmetic half as often as 1024 and
+// are 14 % faster on an 8-plane batch (98 against 86 frames/s), equal on a single plane.
+#ifndef WM_INNER_NT
+#define WM_INNER_NT 512
+#endif
+constexpr int INNER_NT = WM_INNER_NT;
 constexpr int INNER_NW = INNER_NT / 64;
+constexpr int INNER_KR = INNER_NT / 32;        // row pairs a thread column covers per pass (stride between a thread's row pairs)
+constexpr int INNER_NB = 32 / INNER_KR;        // 2x2 blocks of G per thread
 
 __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__ partials, const int nch,
                                                       float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits,
@@ -248,6 +263,9 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   __shared__ float R[RP][RP + 1];
   __shared__ float red[INNER_NW];
   const int t = threadIdx.x, p = blockIdx.x;
+#if defined(WM_INNER_DIAG)     // diagnostic build only (tools/): where one inner solve spends its cycles
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, st3 = 0;
+#endif
   partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
   Rout += (size_t)blockIdx.z * gridDim.x * RP * RP;
   maxcos_bits += blockIdx.z;
@@ -256,20 +274,21 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   const float fl2 = floor2[blockIdx.z];
   const float* src = partials + (size_t)p * nch * RP * RP;
   {
-    // sum the column-chunk partials: independent loads in flight (4 elements x 4 chunks)
+    // sum the column-chunk partials: 32 independent loads in flight
     constexpr int PER = RP * RP / INNER_NT;
+    constexpr int UN = 32 / PER;
     float acc[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) acc[i] = 0.0f;
     int ch = 0;
-    for (; ch + 4 <= nch; ch += 4) {
-      float v[4][PER];
+    for (; ch + UN <= nch; ch += UN) {
+      float v[UN][PER];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < UN; ++u)
 #pragma unroll
         for (int i = 0; i < PER; ++i) v[u][i] = src[(size_t)(ch + u) * RP * RP + t + INNER_NT * i];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < UN; ++u)
 #pragma unroll
         for (int i = 0; i < PER; ++i) acc[i] += v[u][i];
     }
@@ -284,6 +303,9 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
     }
   }
   __syncthreads();
+#if defined(WM_INNER_DIAG)
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
   float mx = 0.0f;
   for (int e = t; e < RP * RP; e += INNER_NT) {
     const int r = e >> 6, c = e & 63;
@@ -311,20 +333,45 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   __syncthreads();
   if (s_skip) return;
 
-  // thread -> one 2x2 block (k1, k2) of G and two (row, pair) items of R.
-  // Every lane computes the rotation of pair (lane & 31) - the wave's two halves redundantly - so
-  // the rotation of the thread's COLUMN pair k2 = t & 31 is already in its registers, and the one
-  // of its ROW pair k1 = t >> 5 (uniform per half-wave) comes from lane k1 by v_readlane: no
-  // rotation table in LDS, one workgroup barrier per step.
-  const int k1 = t >> 5, k2 = t & 31;
+  // Every lane computes the rotation of pair (lane & 31) - the wave's two halves redundantly - so the
+  // rotation of the thread's COLUMN pair k2 is in its own registers, and those of its ROW pairs
+  // kr + KR i (kr uniform per half-wave) come from lanes kr + KR i by v_readlane: no rotation table in
+  // LDS, one workgroup barrier per step.
+  const int k2 = t & 31;
   const int wv_s = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool hi = (t & 32) != 0;
+  const int kr = 2 * wv_s + (hi ? 1 : 0);
   const int n_inner = cross_only ? RB : RP - 1;
+#if defined(WM_INNER_DIAG)
+  st2 = __builtin_amdgcn_s_memtime();
+#endif
   for (int step = 0; step < n_inner; ++step) {
-    const int a = cross_only ? k2 : rr_elem(k2, step);
-    const int b = cross_only ? RB + ((k2 + step) & (RB - 1)) : rr_elem(RP - 1 - k2, step);
-    const int p2 = min(a, b), q2 = max(a, b);
+    float (*Gn)[RP + 1] = GG[(step + 1) & 1];
+    // ---- indices of this step's pairs (cross_only: block-I row k with block-J row (k + step) mod 32) ----
+    const int a2 = cross_only ? k2 : rr_elem(k2, step);
+    const int b2 = cross_only ? RB + ((k2 + step) & (RB - 1)) : rr_elem(RP - 1 - k2, step);
+    const int p2 = min(a2, b2), q2 = max(a2, b2);
+    int p1[INNER_NB], q1[INNER_NB];
+#pragma unroll
+    for (int i = 0; i < INNER_NB; ++i) {
+      const int k1 = kr + INNER_KR * i;
+      const int a1 = cross_only ? k1 : rr_elem(k1, step);
+      const int b1 = cross_only ? RB + ((k1 + step) & (RB - 1)) : rr_elem(RP - 1 - k1, step);
+      p1[i] = min(a1, b1); q1[i] = max(a1, b1);
+    }
+    // ---- every LDS read of the step, issued before the angle arithmetic ----
     const float app = G[p2][p2], aqq = G[q2][q2], apq = G[p2][q2];
+    float g[INNER_NB][4], rp_[2 * INNER_NB], rq_[2 * INNER_NB];
+#pragma unroll
+    for (int i = 0; i < INNER_NB; ++i) {
+      g[i][0] = G[p1[i]][p2]; g[i][1] = G[p1[i]][q2]; g[i][2] = G[q1[i]][p2]; g[i][3] = G[q1[i]][q2];
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * INNER_NB; ++j) {
+      const int r = kr + INNER_KR * j;
+      rp_[j] = R[r][p2]; rq_[j] = R[r][q2];
+    }
+    // ---- rotation of column pair k2 ----
     const float tau = aqq - app, g2 = apq + apq;
     const float ta = fabsf(tau) + 1e-18f;   // all-zero (padding) rows: cos = 1, sin = 0
     const float ih = __builtin_amdgcn_rsqf(fmaf(g2, g2, ta * ta));   // 1/h, h^2 = tau^2 + 4 apq^2
@@ -338,37 +385,43 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
     const bool sw = tau > 0.0f;                                      // de Rijk: larger diagonal to p
     // X[:,p] <- C x_p - S x_q ; X[:,q] <- S x_p + C x_q   (same convention as the tile kernels)
     const float C2 = sw ? s0 : c0, S2 = sw ? -c0 : -s0;
-    // row pair k1 = 2 * wave + (lane >> 5): its rotation and indices live in lanes 2 wave, 2 wave + 1
-    // (the builtin moves 32-bit integers: floats go through their bit patterns)
-    const float C1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), 2 * wv_s));
-    const float C1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), 2 * wv_s + 1));
-    const float S1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), 2 * wv_s));
-    const float S1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), 2 * wv_s + 1));
-    const int p1a = __builtin_amdgcn_readlane(p2, 2 * wv_s), p1b = __builtin_amdgcn_readlane(p2, 2 * wv_s + 1);
-    const int q1a = __builtin_amdgcn_readlane(q2, 2 * wv_s), q1b = __builtin_amdgcn_readlane(q2, 2 * wv_s + 1);
-    const float C1 = hi ? C1b : C1a, S1 = hi ? S1b : S1a;
-    const int p1 = hi ? p1b : p1a, q1 = hi ? q1b : q1a;
-    float (*Gn)[RP + 1] = GG[(step + 1) & 1];
-    // G <- J^T G J on the 2x2 block (rows of pair k1, columns of pair k2)
-    {
-      const float gpp = G[p1][p2], gpq = G[p1][q2], gqp = G[q1][p2], gqq = G[q1][q2];
+    // ---- G <- J^T G J on the thread's 2x2 blocks (rows of pair kr + 8 i, columns of pair k2) ----
+#pragma unroll
+    for (int i = 0; i < INNER_NB; ++i) {
+      const int la = 2 * wv_s + INNER_KR * i;                        // wave-uniform lane holding the row pair's rotation
+      const float C1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), la));
+      const float C1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), la + 1));
+      const float S1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), la));
+      const float S1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), la + 1));
+      const float C1 = hi ? C1b : C1a, S1 = hi ? S1b : S1a;
+      const float gpp = g[i][0], gpq = g[i][1], gqp = g[i][2], gqq = g[i][3];
       const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;   // row p1, columns rotated
       const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;   // row q1
-      Gn[p1][p2] = C1 * a0 - S1 * b0; Gn[p1][q2] = C1 * a1 - S1 * b1;    // rows rotated
-      Gn[q1][p2] = S1 * a0 + C1 * b0; Gn[q1][q2] = S1 * a1 + C1 * b1;
-      // R <- R J : rows k1 and k1 + 32, column pair k2
+      Gn[p1[i]][p2] = C1 * a0 - S1 * b0; Gn[p1[i]][q2] = C1 * a1 - S1 * b1;    // rows rotated
+      Gn[q1[i]][p2] = S1 * a0 + C1 * b0; Gn[q1[i]][q2] = S1 * a1 + C1 * b1;
+    }
+    // ---- R <- R J : rows kr + 8 j, column pair k2 ----
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = k1 + 32 * i;
-        const float rp = R[r][p2], rq = R[r][q2];
-        R[r][p2] = C2 * rp - S2 * rq; R[r][q2] = S2 * rp + C2 * rq;
-      }
+    for (int j = 0; j < 2 * INNER_NB; ++j) {
+      const int r = kr + INNER_KR * j;
+      R[r][p2] = C2 * rp_[j] - S2 * rq_[j]; R[r][q2] = S2 * rp_[j] + C2 * rq_[j];
     }
     __syncthreads();
     G = Gn;
   }
+#if defined(WM_INNER_DIAG)
+  st3 = __builtin_amdgcn_s_memtime();
+#endif
   float* out = Rout + (size_t)p * RP * RP;
   for (int e = t; e < RP * RP; e += INNER_NT) out[e] = R[e >> 6][e & 63];
+#if defined(WM_INNER_DIAG)
+  __syncthreads();
+  if (t == 0 && p == 1 && blockIdx.z == 0) {
+    const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+    printf("inner diag: load %llu maxcos %llu loop %llu (%d steps, %llu per step) store %llu cycles\n", st1 - st0, st2 - st1,
+           st3 - st2, n_inner, (st3 - st2) / (unsigned long long)n_inner, st4 - st3);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
