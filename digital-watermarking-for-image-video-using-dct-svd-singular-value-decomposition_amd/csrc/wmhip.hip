@@ -54,6 +54,28 @@ namespace {
 
 constexpr int N_SUMS = 5;          // detect: sum a, b, ab, aa, bb
 
+// The iteration every tile kernel spends its time in (B = X V by one-sided Jacobi) is a generated,
+// hand-scheduled gfx950 stream with pinned registers (tools/gen_jacobi_asm.py); -DWM_NO_ASM_JACOBI
+// builds the C++ form of wm_tile_math.h instead (A/B, and what the CPU harness tests).
+#if !defined(WM_NO_ASM_JACOBI)
+#include "wm_jacobi_gfx950.inc"
+#endif
+
+// singular values of a raw tile (sigma-only kernels: K2, extract, detect); < 0: sweep bound hit
+__device__ __forceinline__ int sigma_tile_dev(const wm::RawTile& raw, float (&s)[8]) {
+#if !defined(WM_NO_ASM_JACOBI)
+  wm::v2f a[4][8];
+  float n2[8];
+  // sigma only: test from the 3rd sweep on at cos^2 <= 1e-3 (the values are an order ahead of the vectors), no pair skipping
+  const unsigned long long more = jacobi_cols_gfx950(raw.lo, raw.hi, a, n2, wm::JAC_CONV2_SIGMA, 0.0f, 3, 1 << 20);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = wm::fsqrt(n2[i]);
+  return more ? -1 : 1;
+#else
+  return wm::sigma_tile_pk(raw, s);
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // tile I/O (per lane)
 // ---------------------------------------------------------------------------
@@ -262,7 +284,12 @@ __device__ __forceinline__ void embed_group(
   {
     wm::RawTile raw;
     load_raw<ALIGNED>(host + off, g.row_stride, raw);
+#if !defined(WM_NO_ASM_JACOBI)
+    // sweeps 1-3 run untested, the 4th is the first that can be the last, pairs are skipped from the 5th on
+    sweeps = jacobi_cols_gfx950(raw.lo, raw.hi, a, n2, wm::JAC_CONV2, wm::JAC_SKIP2, 4, 4) ? -1 : 1;
+#else
     sweeps = wm::embed_jacobi_pk(raw, a, n2);
+#endif
   }
   // Only B (64 VGPRs) crosses the sweep loop; everything else is (re)loaded when it is used
   // and stored as soon as it is final, so that the kernel fits 128 VGPRs (4 waves per SIMD):
@@ -392,7 +419,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_sigma_tiles(const uint8_t* __restri
   float s[8];
   load_raw<ALIGNED>(planes + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
                     g.row_stride, raw);
-  if (wm::sigma_tile_pk(raw, s) < 0) atomicOr(status, 1);
+  if (sigma_tile_dev(raw, s) < 0) atomicOr(status, 1);
   store_row8_f32<true>(sigma + (plane * g.n_tiles + t) * 8, s);
 }
 
@@ -450,7 +477,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
   float a[8][8], s[8], sc[8], keep[8];
   load_raw<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
                     g.row_stride, raw);
-  if (wm::sigma_tile_pk(raw, s) < 0) atomicOr(status, 1);
+  if (sigma_tile_dev(raw, s) < 0) atomicOr(status, 1);
   load_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
 #pragma unroll
   for (int i = 0; i < 8; ++i) keep[i] = (i < K) ? 1.0f : 0.0f;
@@ -536,7 +563,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_detect_tiles(
     float s[8], sc[8], sw[8];
     load_raw<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
                       g.row_stride, raw);
-    if (wm::sigma_tile_pk(raw, s) < 0) atomicOr(status, 1);
+    if (sigma_tile_dev(raw, s) < 0) atomicOr(status, 1);
     load_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
     load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
 #pragma unroll
