@@ -399,6 +399,25 @@ GaussTaps make_taps() {     // cv2.getGaussianKernel(11, 1.5)
 
 }  // namespace
 
+// ---- keyed scramble / unscramble of the watermark plane (single:66-80) ---------------------------
+// The permutation itself stays NumPy's PCG64 shuffle on the host (bit-exact by construction); only the two
+// index passes run here:  _permute: dst[i] = src[idx[i]]   _unpermute: dst[idx[i]] = src[i]
+template <typename T>
+__global__ __launch_bounds__(256) void k_permute(const T* __restrict__ src, const int* __restrict__ idx,
+                                                float* __restrict__ dst, const size_t n, const size_t plane_stride_src) {
+  src += (size_t)blockIdx.y * plane_stride_src;
+  dst += (size_t)blockIdx.y * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (float)src[idx[i]];
+}
+__global__ __launch_bounds__(256) void k_unpermute(const float* __restrict__ src, const int* __restrict__ idx,
+                                                  float* __restrict__ dst, const size_t n) {
+  src += (size_t)blockIdx.y * n;
+  dst += (size_t)blockIdx.y * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[idx[i]] = src[i];
+}
+
 extern "C" {
 
 int wm_bgr_to_ycrcb_u8_dev(wm_ctx* ctx, const uint8_t* bgr, uint8_t* ycrcb, size_t n_px) {
@@ -475,6 +494,40 @@ int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint
   const unsigned n_part = grid_for(n / 4 + 1, 256, MINMAX_BLOCKS);
   if (do_norm) hipLaunchKernelGGL(k_minmax, dim3(n_part), dim3(256), 0, ctx->stream, x, n, mm);
   hipLaunchKernelGGL(k_normalize_u8, dim3(grid_for(n / 4 + 1)), dim3(256), 0, ctx->stream, x, n, mm, n_part, do_norm, out);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+static int check_perm_args(wm_ctx* ctx, const void* src, const int* idx, const float* dst, size_t n, int n_planes) {
+  WM_TRY(wmi::use_ctx(ctx));
+  if (n_planes < 0 || n_planes > 65535) return set_err(WM_ERR_BADARG, "n_planes must be in 0..65535");
+  if (n > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 - 1 elements per plane (the index is int32)");
+  if (n && n_planes && (!src || !idx || !dst)) return set_err(WM_ERR_BADARG, "NULL argument");
+  return WM_OK;
+}
+
+int wm_permute_u8_f32_dev(wm_ctx* ctx, const uint8_t* src, const int* idx, float* dst, size_t n, int n_planes) {
+  WM_TRY(check_perm_args(ctx, src, idx, dst, n, n_planes));
+  if (n == 0 || n_planes == 0) return WM_OK;
+  hipLaunchKernelGGL((k_permute<uint8_t>), dim3(grid_for(n), n_planes), dim3(256), 0, ctx->stream, src, idx, dst, n, n);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+int wm_permute_f32_dev(wm_ctx* ctx, const float* src, const int* idx, float* dst, size_t n, int n_planes) {
+  WM_TRY(check_perm_args(ctx, src, idx, dst, n, n_planes));
+  if (n == 0 || n_planes == 0) return WM_OK;
+  if (src == dst) return set_err(WM_ERR_BADARG, "permute cannot run in place");
+  hipLaunchKernelGGL((k_permute<float>), dim3(grid_for(n), n_planes), dim3(256), 0, ctx->stream, src, idx, dst, n, n);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+
+int wm_unpermute_f32_dev(wm_ctx* ctx, const float* src, const int* idx, float* dst, size_t n, int n_planes) {
+  WM_TRY(check_perm_args(ctx, src, idx, dst, n, n_planes));
+  if (n == 0 || n_planes == 0) return WM_OK;
+  if (src == dst) return set_err(WM_ERR_BADARG, "unpermute cannot run in place");
+  hipLaunchKernelGGL(k_unpermute, dim3(grid_for(n), n_planes), dim3(256), 0, ctx->stream, src, idx, dst, n);
   WM_HIP(hipGetLastError());
   return WM_OK;
 }

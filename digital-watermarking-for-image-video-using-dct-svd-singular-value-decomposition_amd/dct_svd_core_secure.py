@@ -87,7 +87,7 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
                   tile=np.int32(TILE), k_floor=np.int32(k_floor))
     if color:
         hosts = np.ascontiguousarray(np.moveaxis(cover, -1, 0))            # b, g, r planes  single:122
-        wms = np.stack([hg.permute(wm[..., ch].astype(np.float32), idx) for ch in range(3)])  # single:123-126
+        wms = ctx.permute_planes(np.ascontiguousarray(np.moveaxis(wm, -1, 0)), idx)              # single:123-126 (index pass on the device)
         U, S, Vt = ctx.svd_tiles(wms)                                      # single:131-134
         stego_p, Sc, _ = ctx.embed_tiles(hosts, S, alpha, K)               # single:127-147
         stego = np.ascontiguousarray(np.moveaxis(stego_p, 0, -1))
@@ -102,7 +102,7 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
         return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
                     ssim=ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego)))   # single:167
     Y = ctx.color("bgr2y", cover)                                          # single:169  (_to_Y)
-    wy_s = hg.permute(ctx.color("bgr2gray", wm).astype(np.float32), idx)   # single:170-171
+    wy_s = ctx.permute_planes(ctx.color("bgr2gray", wm), idx)              # single:170-171 (index pass on the device)
     Uw, Sw, Vwt = ctx.svd_tiles(wy_s)                                      # single:173
     stegoY, Sc, Yw = ctx.embed_tiles(Y, Sw, alpha, K, want_yw=True)        # single:172-177
     stego = ctx.color("replace_y", cover, stegoY)                          # single:26-30 (_from_Y)
@@ -127,7 +127,7 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
         meta = dict(mode="color", **common)
         Sws = []
         for ch, n in enumerate("bgr"):                                     # single:123-134
-            w_s = hg.permute(wm[..., ch].astype(np.float32), idx)
+            w_s = ctx.permute_planes(np.ascontiguousarray(wm[..., ch]), idx)
             U, S, Vt = ctx.ref_svd(w_s, apply_dct=True)
             meta["UW" + n] = U; meta["VW" + n + "t"] = Vt; meta["SW" + n] = S
             Sws.append(S)
@@ -142,7 +142,7 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
         return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
                     ssim=ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego)))
     Y = ctx.color("bgr2y", cover)
-    wy_s = hg.permute(ctx.color("bgr2gray", wm).astype(np.float32), idx)
+    wy_s = ctx.permute_planes(ctx.color("bgr2gray", wm), idx)
     Uw, Sw, Vwt = ctx.ref_svd(wy_s, apply_dct=True)                        # single:173
     stegoY, Sc, Yw = ctx.ref_embed(Y, Sw, alpha, K, want_yw=True)          # single:172-177
     stego = ctx.color("replace_y", cover, stegoY)
@@ -204,19 +204,14 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
     K = _k_of(TILE, kfrac, k_floor)
     if mode == "gray":
         Y = ctx.color("bgr2y", stego)                                      # single:204
-        wy_s = ctx.extract_tiles(Y, meta["Sc"], meta["Uw"], meta["Vwt"], alpha, K)   # single:205-218
-        wy = hg.unpermute(wy_s, idx)                                       # single:220
-        return ctx.normalize_u8(wy, normalize)                             # single:221-222
+        # single:205-222 in one device-resident chain: sigma -> rank-8 product -> unscramble -> normalise -> uint8
+        return ctx.extract_tiles_unscrambled_u8(Y, meta["Sc"], meta["Uw"], meta["Vwt"], alpha, K, idx, normalize)
     planes = np.ascontiguousarray(np.moveaxis(stego, -1, 0))               # single:232
     Sc = np.stack([meta["S" + n] for n in "bgr"])
     U = np.stack([meta["UW" + n] for n in "bgr"])
     Vt = np.stack([meta["VW" + n + "t"] for n in "bgr"])
-    ws = ctx.extract_tiles(planes, Sc, U, Vt, alpha, K)                    # single:233-264
-    outs = []
-    for ch in range(3):
-        w = hg.unpermute(ws[ch], idx)                                      # single:266-267
-        outs.append(ctx.normalize_u8(w, normalize))                        # single:269-274
-    return np.stack(outs, axis=-1)
+    ws = ctx.extract_tiles_unscrambled_u8(planes, Sc, U, Vt, alpha, K, idx, normalize)   # single:233-274
+    return np.ascontiguousarray(np.moveaxis(ws, 0, -1))
 
 
 def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, W, idx, normalize):
@@ -227,13 +222,13 @@ def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, 
         Y = ctx.color("bgr2y", stego)
         Uw, Vwt = meta["Uw"], meta["Vwt"]
         wy_s = ctx.ref_extract(Y, meta["Sc"], Uw, Vwt, alpha, k_for(meta["Sc"], Uw.shape[0], Vwt.shape[0]))
-        return ctx.normalize_u8(hg.unpermute(wy_s, idx), normalize)
+        return ctx.unpermute_normalize_u8(wy_s, idx, normalize)
     outs = []
     for ch, n in enumerate("bgr"):
         U, Vt, Sc = meta["UW" + n], meta["VW" + n + "t"], meta["S" + n]
         w_s = ctx.ref_extract(np.ascontiguousarray(stego[..., ch]), Sc, U, Vt, alpha,
                               k_for(Sc, U.shape[0], Vt.shape[0]))
-        outs.append(ctx.normalize_u8(hg.unpermute(w_s, idx), normalize))
+        outs.append(ctx.unpermute_normalize_u8(w_s, idx, normalize))
     return np.stack(outs, axis=-1)
 
 

@@ -93,6 +93,9 @@ SIGNATURES = {
     "wm_sqdiff_u8_dev": [_vp, _vp, _vp, _sz, _vp],
     "wm_ssim_dev": [_vp, _vp, _sz, _vp, _sz, _i, _i, _i, _vp],
     "wm_normalize_u8_dev": [_vp, _vp, _sz, _i, _vp],
+    "wm_permute_u8_f32_dev": [_vp, _vp, _vp, _vp, _sz, _i],
+    "wm_permute_f32_dev": [_vp, _vp, _vp, _vp, _sz, _i],
+    "wm_unpermute_f32_dev": [_vp, _vp, _vp, _vp, _sz, _i],
     "wm_color_u8": [_vp, _i, _vp, _vp, _vp, _vp, _sz],
     "wm_psnr_u8": [_vp, _vp, _vp, _sz, C.POINTER(C.c_double)],
     "wm_ssim": [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_double)],
@@ -181,6 +184,11 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for _, d in self.__dict__.pop("_idx_cache", []):
+                try:
+                    self.free(d)
+                except Exception:
+                    pass
             self.lib.wm_destroy(self._h)
             self._h = None
 
@@ -529,6 +537,111 @@ class Context:
         self._call("wm_ref_detect_planes_u8", _vp(stegos.ctypes.data), _vp(sc.ctypes.data), _vp(sw.ctypes.data),
                    _vp(scores.ctypes.data), n, H, W, W, H * W, float(alpha))
         return scores
+
+    # ---- keyed scramble / unscramble on the device (single:66-80) ------------------
+    # The permutation is NumPy's own PCG64 shuffle (hostglue.permutation_index, bit-exact by construction);
+    # its int32 copy is uploaded once per index array and kept (two entries, like the host-side cache).
+    def index_dev(self, idx: np.ndarray) -> int:
+        cache = self.__dict__.setdefault("_idx_cache", [])
+        tag = (idx.__array_interface__["data"][0], idx.size, int(idx[0]), int(idx[-1]), int(idx[idx.size // 2]))
+        for t, d in cache:
+            if t == tag:
+                return d
+        if idx.size > 0x7fffffff:
+            raise ValueError("plane too large for an int32 index")
+        i32 = np.ascontiguousarray(idx, dtype=np.int32)
+        d = self.malloc(max(i32.nbytes, 4))
+        self.h2d(d, i32)
+        cache.append((tag, d))
+        while len(cache) > 2:
+            _, old = cache.pop(0)
+            self.sync()
+            self.free(old)
+        return d
+
+    def permute_planes(self, planes: np.ndarray, idx: np.ndarray) -> np.ndarray:
+        """``flat[idx]`` of every plane (uint8 or float32 [H, W] / [n, H, W]) -> float32, like hostglue.permute."""
+        single = planes.ndim == 2
+        p = np.ascontiguousarray(planes[None] if single else planes)
+        n_pl, H, W = p.shape
+        n = H * W
+        if idx.size != n:
+            raise ValueError("index length does not match the plane")
+        d_idx = self.index_dev(idx)
+        d_src = self.malloc(p.nbytes); d_dst = self.malloc(n_pl * n * 4)
+        try:
+            self.h2d(d_src, p)
+            if p.dtype == np.uint8:
+                self._call("wm_permute_u8_f32_dev", _vp(d_src), _vp(d_idx), _vp(d_dst), n, n_pl)
+            elif p.dtype == np.float32:
+                self._call("wm_permute_f32_dev", _vp(d_src), _vp(d_idx), _vp(d_dst), n, n_pl)
+            else:
+                raise ValueError("planes must be uint8 or float32")
+            out = np.empty((n_pl, H, W), np.float32)
+            self.d2h(out, d_dst)
+        finally:
+            self.free(d_src); self.free(d_dst)
+        return out[0] if single else out
+
+    def unpermute_normalize_u8(self, planes: np.ndarray, idx: np.ndarray, normalize: bool = True) -> np.ndarray:
+        """hostglue.unpermute + the reference's min-max normalise / clip / uint8 (single:220-222) per plane, on the
+        device: float32 [H, W] / [n, H, W] in, uint8 out."""
+        single = planes.ndim == 2
+        p = np.ascontiguousarray(planes[None] if single else planes, dtype=np.float32)
+        n_pl, H, W = p.shape
+        d_src = self.malloc(p.nbytes)
+        try:
+            self.h2d(d_src, p)
+            out = self._unpermute_normalize_dev(d_src, n_pl, H, W, idx, normalize)
+        finally:
+            self.free(d_src)
+        return out[0] if single else out
+
+    def _unpermute_normalize_dev(self, d_src: int, n_pl: int, H: int, W: int, idx: np.ndarray, normalize: bool) -> np.ndarray:
+        n = H * W
+        if idx.size != n:
+            raise ValueError("index length does not match the plane")
+        d_idx = self.index_dev(idx)
+        n_pad = (n + 3) & ~3                      # the normalise kernel reads float4: every plane starts 16-byte aligned
+        d_tmp = self.malloc(n_pl * n_pad * 4); d_u8 = self.malloc(n_pl * n_pad)
+        try:
+            out = np.empty((n_pl, H, W), np.uint8)
+            for z in range(n_pl):      # the reference normalises every plane on its own (single:269-274)
+                self._call("wm_unpermute_f32_dev", _vp(d_src + z * n * 4), _vp(d_idx), _vp(d_tmp + z * n_pad * 4), n, 1)
+                self._call("wm_normalize_u8_dev", _vp(d_tmp + z * n_pad * 4), n, 1 if normalize else 0,
+                           _vp(d_u8 + z * n_pad))
+                self.d2h(out[z], d_u8 + z * n_pad)
+        finally:
+            self.free(d_tmp); self.free(d_u8)
+        return out
+
+    def extract_tiles_unscrambled_u8(self, stego: np.ndarray, sigma_c: np.ndarray, Uw: np.ndarray, Vwt: np.ndarray,
+                                     alpha: float, K: int, idx: np.ndarray, normalize: bool = True) -> np.ndarray:
+        """extract_tiles + unpermute + normalise without the float plane ever leaving the device
+        (single:204-222 / 232-274): uint8 stego planes in, uint8 watermark planes out."""
+        if stego.dtype != np.uint8:
+            raise ValueError("stego planes must be uint8")
+        single = stego.ndim == 2
+        st = np.ascontiguousarray(stego[None] if single else stego)
+        n, H, W = st.shape
+        nby, nbx = H // TILE, W // TILE
+        sc = np.ascontiguousarray(sigma_c, dtype=np.float32)
+        Uw = np.ascontiguousarray(Uw, dtype=np.float32); Vwt = np.ascontiguousarray(Vwt, dtype=np.float32)
+        per_plane = Uw.ndim == 5
+        if sc.size != n * nby * nbx * 8 or Uw.shape[-4:] != (nby, nbx, 8, 8) or Vwt.shape != Uw.shape \
+                or (per_plane and Uw.shape[0] != n):
+            raise ValueError("meta arrays do not match the planes")
+        bufs = [self.malloc(max(x, 16)) for x in (st.nbytes, sc.nbytes, Uw.nbytes, Vwt.nbytes, n * H * W * 4)]
+        d_st, d_sc, d_u, d_v, d_w = bufs
+        try:
+            self.h2d(d_st, st); self.h2d(d_sc, sc); self.h2d(d_u, Uw); self.h2d(d_v, Vwt)
+            self.extract_tiles_u8_dev(d_st, d_sc, d_u, d_v, d_w, n, H, W, W, H * W, nby * nbx if per_plane else 0,
+                                      float(alpha), int(K))
+            out = self._unpermute_normalize_dev(d_w, n, H, W, idx, normalize)
+        finally:
+            for b in bufs:
+                self.free(b)
+        return out[0] if single else out
 
     # ---- pixel-side kernels (colour, PSNR, SSIM, normalise) ----------------------
     _COLOR_OPS = {"bgr2ycrcb": 0, "ycrcb2bgr": 1, "bgr2gray": 2, "bgr2y": 3, "replace_y": 4}

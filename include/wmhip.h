@@ -276,6 +276,14 @@ int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2,
 /* uint8(clip(cv2.normalize(x, 0, 255, NORM_MINMAX), 0, 255))  (single:221-222); do_norm=0: clip only.
  * x must be 16-byte aligned (any wm_malloc'd plane is). */
 int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint8_t* out);
+/* Keyed scramble / unscramble of the watermark plane, single:66-80 (`_permute`: flat[idx];
+ * `_unpermute`: inv[idx] = arange; flat[inv]).  idx is the int32 copy of the permutation NumPy's
+ * PCG64 shuffle produced on the host (bit-exact there by construction; this is only the index pass).
+ * n elements per plane, n_planes planes share idx; dst float32 [n_planes][n], never in place.
+ *   permute:    dst[i] = (float) src[idx[i]]        unpermute:  dst[idx[i]] = src[i] */
+int wm_permute_u8_f32_dev(wm_ctx* ctx, const uint8_t* src, const int* idx, float* dst, size_t n, int n_planes);
+int wm_permute_f32_dev(wm_ctx* ctx, const float* src, const int* idx, float* dst, size_t n, int n_planes);
+int wm_unpermute_f32_dev(wm_ctx* ctx, const float* src, const int* idx, float* dst, size_t n, int n_planes);
 /* host-pointer conveniences; op: 0 BGR->YCrCb, 1 YCrCb->BGR, 2 BGR->gray plane, 3 BGR->Y plane,
  * 4 replace Y (plane_in) and return BGR */
 int wm_color_u8(wm_ctx* ctx, int op, const uint8_t* in3, const uint8_t* plane_in, uint8_t* out3,

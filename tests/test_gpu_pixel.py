@@ -44,3 +44,35 @@ def test_psnr_ssim_normalize(gpu_ctx):
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and np.mean(got != want) < 1e-3
     assert np.array_equal(gpu_ctx.normalize_u8(x, False), np.clip(x, 0, 255).astype(np.uint8))
     assert np.array_equal(gpu_ctx.normalize_u8(np.full((4, 4), 3.0, np.float32), True), np.zeros((4, 4), np.uint8))
+
+
+def test_device_scramble_and_unscramble_are_bit_identical_to_the_host_glue(gpu_ctx):
+    """single:66-80 on the device: the permutation stays NumPy's PCG64 shuffle (host, bit-exact by construction),
+    the two index passes - flat[idx] and the inverse scatter - and the normalise that follows run as kernels.
+    Bit for bit the host glue's result, for uint8 and float32 planes, one plane and three."""
+    import importlib
+    from conftest import PKG_NAME
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    rng = np.random.default_rng(17)
+    for (H, W) in ((40, 56), (1080, 1920)):
+        key = hg.derive_key("pw", bytes(range(8)))
+        idx = hg.permutation_index(H, W, key)
+        g8 = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        assert np.array_equal(gpu_ctx.permute_planes(g8, idx), hg.permute(g8.astype(np.float32), idx))
+        f3 = rng.uniform(-50, 300, (3, H, W)).astype(np.float32)
+        p3 = gpu_ctx.permute_planes(f3, idx)
+        for z in range(3):
+            assert np.array_equal(p3[z], hg.permute(f3[z], idx))
+        for norm in (True, False):
+            u3 = gpu_ctx.unpermute_normalize_u8(f3, idx, norm)
+            for z in range(3):
+                want = gpu_ctx.normalize_u8(hg.unpermute(f3[z], idx), norm)     # the round-1 path: host scatter, device normalise
+                assert np.array_equal(u3[z], want)
+        assert np.array_equal(gpu_ctx.unpermute_normalize_u8(p3[0], idx, False),
+                              np.clip(f3[0], 0, 255).astype(np.uint8))          # unpermute(permute(x)) == x
+    # a second key on the same context: the device index cache must not hand out the first key's index
+    idx2 = hg.permutation_index(40, 56, hg.derive_key("other", bytes(8)))
+    g8 = rng.integers(0, 256, (40, 56), dtype=np.uint8)
+    assert np.array_equal(gpu_ctx.permute_planes(g8, idx2), hg.permute(g8.astype(np.float32), idx2))
+    with pytest.raises(ValueError):
+        gpu_ctx.permute_planes(g8, idx2[:-1])
