@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--ff-height", type=int, default=1080)
     ap.add_argument("--ff-width", type=int, default=1920)
     ap.add_argument("--no-fullframe", action="store_true", help="skip the full-frame section of the default line")
+    ap.add_argument("--quick", action="store_true",
+                    help="the contract line only: skip the end-to-end, pool / reference-semantics CPU and full-frame sections")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a 1-GPU box)")
@@ -89,6 +91,115 @@ def cpu_baseline(frames_u8, wys, alpha, stego_gpu, sc_gpu, wm_gpu):
                 host_cpus=os.cpu_count()), \
         dict(stego_max_lsb=worst_lsb, sigma_max_rel=worst_sig, extract_max_rel_to_range=worst_wm,
              psnr_cpu=float(np.mean(psnr_cpu)), psnr_gpu=float(np.mean(psnr_gpu)))
+
+
+_POOL = {}
+
+
+def _pool_init(H, W):
+    """worker start-up (untimed): the watermark's tile SVD, once per worker like once per video on the GPU"""
+    from oracle import wm_oracle as o
+    _POOL["o"] = o
+    _POOL["wys"] = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+    _POOL["svd"] = o.watermark_decompose(_POOL["wys"], 8)
+
+
+def _pool_ready(_):
+    return os.getpid()
+
+
+def _pool_frame(args):
+    frame, alpha = args
+    o = _POOL["o"]
+    H, W = frame.shape
+    e = o.embed_plane(frame.astype(np.float32), _POOL["wys"], alpha, 0.6, tile=8, wm_svd=_POOL["svd"])
+    o.extract_plane(e["stego"].astype(np.float32), e["Sc"], e["Uw"], e["Vwt"], alpha, 0.6, H, W, 8)
+    return int(e["stego"][0, 0])
+
+
+def cpu_baseline_pool(frames_u8, alpha):
+    """The same tile-mode oracle under a process pool over frames: one frame per worker, as many workers as this
+    process may run on (capped at 16 - the GPU box's CPU share per GPU).  Workers are spawned (the parent holds a
+    HIP context), start-up and the per-worker watermark SVD are outside the timed region."""
+    import multiprocessing as mp
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nw = max(1, min(avail, 16, frames_u8.shape[0]))
+    H, W = frames_u8.shape[1:]
+    with mp.get_context("spawn").Pool(nw, initializer=_pool_init, initargs=(H, W)) as pool:
+        pool.map(_pool_ready, range(4 * nw), chunksize=1)                 # every worker is up and initialised
+        t0 = time.perf_counter()
+        pool.map(_pool_frame, [(frames_u8[i], alpha) for i in range(nw)], chunksize=1)
+        wall = time.perf_counter() - t0
+    return dict(value=nw / wall, unit="frames/s", cores=nw, kind="port",
+                sample=f"{nw} frames, one per worker process: NumPy oracle tile-mode embed+extract", host_cpus=os.cpu_count(),
+                cpus_available=avail)
+
+
+def cpu_reference_semantics(frame_u8, wys, alpha):
+    """What the REFERENCE itself does to one frame of this size (single:172-177, 205-218: one dense DCT + SVD of the
+    whole plane, twice per embed - host and watermark - and once per extract), through the oracle's tile=None path;
+    LAPACK threads as NumPy finds them."""
+    from oracle import wm_oracle as o
+    H, W = frame_u8.shape
+    t0 = time.perf_counter(); c0 = time.process_time()
+    e = o.embed_plane(frame_u8.astype(np.float32), wys, alpha, 0.6, None)
+    t1 = time.perf_counter()
+    o.extract_plane(e["stego"].astype(np.float32), e["Sc"], e["Uw"], e["Vwt"], alpha, 0.6, H, W, None)
+    wall = time.perf_counter() - t0
+    cores = max(1, round((time.process_time() - c0) / wall))
+    return dict(value=1.0 / wall, unit="frames/s", cores=int(cores), kind="port", embed_s=t1 - t0, extract_s=wall - (t1 - t0),
+                sample=f"1 frame {W}x{H}: the reference's own full-plane path (oracle tile=None) - embed incl. the watermark "
+                       f"SVD + extract", host_cpus=os.cpu_count())
+
+
+def end_to_end_section(torch, api, dev, H, W, alpha, Sw, Ux, Vxt, F=8, batches=12):
+    """PCIe-inclusive tile-mode embed+extract: pinned host frames -> H2D -> K1 embed -> K2+K4 extract -> min-max
+    normalise to uint8 -> D2H of stego, Sc and the extracted plane, double-buffered on two HIP streams (two contexts).
+    Never `value`: the contract's number is device-resident."""
+    nt = (H // 8) * (W // 8)
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    ctxs = [api.Context(dev.index or 0, stream=s_.cuda_stream) for s_ in streams]
+    h_in = [torch.randint(0, 256, (F, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    h_st = [torch.empty((F, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    h_wm = [torch.empty((F, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    h_sc = [torch.empty((F, nt, 8), dtype=torch.float32).pin_memory() for _ in range(2)]
+    d_in = [torch.empty((F, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_st = [torch.empty_like(d_in[0]) for _ in range(2)]
+    d_u8 = [torch.empty_like(d_in[0]) for _ in range(2)]
+    d_sc = [torch.empty((F, nt, 8), dtype=torch.float32, device=dev) for _ in range(2)]
+    d_wm = [torch.empty((F, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+
+    def run(nb):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for b in range(nb):
+            k = b & 1
+            with torch.cuda.stream(streams[k]):
+                d_in[k].copy_(h_in[k], non_blocking=True)
+                ctxs[k].embed_tiles_u8_dev(d_in[k].data_ptr(), Sw.data_ptr(), d_st[k].data_ptr(), d_sc[k].data_ptr(), None,
+                                           F, H, W, W, H * W, 0, alpha, 8)
+                ctxs[k].extract_tiles_px_u8_dev(d_st[k].data_ptr(), d_sc[k].data_ptr(), Ux.data_ptr(), Vxt.data_ptr(),
+                                                d_wm[k].data_ptr(), F, H, W, W, H * W, 0, alpha, 8)
+                for f in range(F):       # the reference normalises every extracted plane on its own (single:221-222)
+                    ctxs[k]._call("wm_normalize_u8_dev", api._vp(d_wm[k][f].data_ptr()), H * W, 1, api._vp(d_u8[k][f].data_ptr()))
+                h_st[k].copy_(d_st[k], non_blocking=True)
+                h_sc[k].copy_(d_sc[k], non_blocking=True)
+                h_wm[k].copy_(d_u8[k], non_blocking=True)
+        torch.cuda.synchronize(dev)
+        return nb * F / (time.perf_counter() - t0)
+
+    run(2)
+    fps = run(batches)
+    for c in ctxs:
+        c.check_status(); c.close()
+    h2d, d2h = H * W, 2 * H * W + nt * 32
+    return dict(value=fps, unit="frames/s", frames_per_batch=F, batches=batches,
+                pcie_bytes_per_frame={"h2d": h2d, "d2h": d2h},
+                pcie_GBps={"h2d": fps * h2d / 1e9, "d2h": fps * d2h / 1e9},
+                note="pinned host memory, two streams double-buffered; frame in, stego + Sc + extracted uint8 plane out")
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 runs at the vector rate)
@@ -390,8 +501,8 @@ def main():
                          "kernel": "k_embed_tiles (+ its fallback pass)", "launch_ms": embed_ms_avg,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "valu": valu,
-                         "note": "path is FP32-VALU-bound (~7.5e3 VALU instructions per 64-tile wave against 192 B "
-                                 "per tile): the HBM fraction cannot approach 1, see DESIGN.md 3.3"},
+                         "note": "path is FP32-VALU-bound (~6.5e3 VALU instructions per 64-tile wave against 192 B "
+                                 "per tile, VALU busy 0.99): the HBM fraction cannot approach 1, see DESIGN.md 3.3"},
         }
         if world == 1 and a.cpu_frames > 0:
             n = min(a.cpu_frames, F)
@@ -401,7 +512,12 @@ def main():
                                    wm_out[:n].cpu().numpy())
             out["cpu_baseline"] = cb
             out["parity"] = par
-        if world == 1 and not a.no_fullframe and (H, W) == (2160, 3840):
+            if not a.quick:
+                out["cpu_baseline_pool"] = cpu_baseline_pool(frames[:16].cpu().numpy(), alpha)
+                out["cpu_baseline_reference_semantics"] = cpu_reference_semantics(frames[0].cpu().numpy(), wys_np, alpha)
+        if world == 1 and not a.quick:
+            out["end_to_end"] = end_to_end_section(torch, api, dev, H, W, alpha, Sw, Ux, Vxt)
+        if world == 1 and not a.no_fullframe and not a.quick and (H, W) == (2160, 3840):
             # after the timed tile-mode region (value / ms_per_step above are untouched): the reference's own
             # full-frame semantics on BASELINE config 2's shape, with its own roofline and CPU baseline
             out["fullframe"] = fullframe_section(a, torch, dist, api, dev, rank, world, ctx, 2, 1,

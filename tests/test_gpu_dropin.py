@@ -284,3 +284,35 @@ def test_array_level_roundtrip_on_odd_sizes(core, tile):
             assert np.isfinite(score)
             if min(H, W) >= 16:
                 assert ok and score > 0.8, (H, W, color, tile, score)
+
+
+@pytest.mark.parametrize("tile", [8, None])
+def test_config1_literal_512_gray_64_logo_alpha_012(core, tmp_path, tile):
+    """BASELINE config 1 with its literal parameters - 512x512 grayscale host, 64x64 watermark (x8 replication by
+    the INTER_AREA resize), alpha = 0.12, kfrac = 0.6 - through the file-level embed_watermark / extract_watermark /
+    detect aliases, against the oracle's array pipeline on the same inputs, in both modes."""
+    hg = __import__("importlib").import_module(core._impl.__package__ + ".hostglue")
+    g = np.random.default_rng(1234).integers(0, 256, (512, 512), dtype=np.uint8)
+    cover = np.stack([g] * 3, axis=-1)                                  # a grayscale host as cv2.imread(IMREAD_COLOR) returns it
+    wm1 = np.random.default_rng(4321).integers(0, 256, (64, 64), dtype=np.uint8)
+    wm = np.stack([wm1] * 3, axis=-1)
+    cp, wp = str(tmp_path / "host.png"), str(tmp_path / "logo.png")
+    assert hg.write_png(cp, cover) and hg.write_png(wp, wm)
+    out, meta, ps, ss = core.embed_watermark(cp, wp, str(tmp_path / "stego.png"), str(tmp_path / "meta.npz"), alpha=0.12,
+                                             color=False, password="bench", nonce=bytes(8), tile=tile)
+    ref = o.embed_arrays(cover, wm, "bench", bytes(8), 0.12, False, 0.6, tile)
+    st = hg.read_image_bgr(out)
+    d = np.abs(st.astype(int) - ref["stego"].astype(int))
+    assert d.max() <= 2 and np.mean(d != 0) < 5e-3                       # 1 LSB on Y, up to 2 after YCrCb -> BGR
+    assert abs(ps - ref["psnr"]) < 2e-2 and abs(ss - ref["ssim"]) < 1e-3
+    data = np.load(meta, allow_pickle=False)
+    sc, sco = data["Sc"], ref["meta"]["Sc"]
+    assert np.max(np.abs(sc - sco) / np.maximum(sco[..., :1] if sco.ndim > 1 else sco[0], 1e-30)) < 1e-4
+    assert np.array_equal(hg.resize_area(wm, 512, 512), np.kron(wm1, np.ones((8, 8), np.uint8))[..., None].repeat(3, -1))
+    wout = core.extract_watermark(out, meta, str(tmp_path / "wm_out.png"), password="bench")
+    ex_o = o.extract_arrays(ref["stego"], ref["meta"], "bench", True, tile)
+    ex = hg.read_image_bgr(wout)[..., 0]
+    assert np.mean(np.abs(ex.astype(int) - ex_o.astype(int)) > 2) < 2e-2
+    ok, score = core.detect(out, meta)
+    so = o.detect_arrays(ref["stego"], ref["meta"], 0.6, tile)[1]
+    assert ok and abs(score - so) < 2e-3

@@ -85,7 +85,7 @@ def test_bench_starts_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
-                        "--height", "64", "--width", "96", "--frames", "4", "--steps", "3", "--warmup", "1"],
+                        "--height", "64", "--width", "96", "--frames", "4", "--steps", "3", "--warmup", "1", "--quick"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]

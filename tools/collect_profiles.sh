@@ -6,7 +6,7 @@
 set -o pipefail
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
-CMD="python bench.py --steps 5 --warmup 2 --cpu-frames 0"
+CMD="python3 bench.py --steps 5 --warmup 2 --cpu-frames 0 --quick"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.json" 2> "$OUT/stats.err" || exit 1

@@ -80,6 +80,17 @@ def main():
                        effective_clock_GHz=out["embed"]["effective_clock_GHz"],
                        valu_insts_per_wave=out["embed"]["valu_insts_per_wave"]),
                   open(os.path.join(prof, "pmc_embed_latest.json"), "w"))
+    x = res.get("k_extract_tiles", {})
+    if "FETCH_SIZE" in x and "WRITE_SIZE" in x:
+        nt = (H // 8) * (W // 8)
+        # reads: stego P + Sc P/2 per plane, the shared pixel-domain factors 8 P once per launch; writes: float32 plane 4 P
+        alg_r = F * (H * W + nt * 32) + 2 * nt * 256
+        alg_w = F * H * W * 4
+        out["extract"] = dict(algorithmic_read_bytes=alg_r, algorithmic_write_bytes=alg_w,
+                              fetch_bytes_raw=x["FETCH_SIZE"] * 1024, fetch_bytes_x2_corrected=x["FETCH_SIZE"] * 2048,
+                              write_bytes=x["WRITE_SIZE"] * 1024,
+                              fetch_x2_over_algorithmic_reads=x["FETCH_SIZE"] * 2048 / alg_r,
+                              avg_us_kernel_trace=x.get("avg_us_kernel_trace"))
     json.dump(out, open(os.path.join(prof, tag + "_summary.json"), "w"), indent=1)
     print(json.dumps(out.get("embed", {}), indent=1))
     print({k: v.get("avg_us_kernel_trace") for k, v in res.items()})
