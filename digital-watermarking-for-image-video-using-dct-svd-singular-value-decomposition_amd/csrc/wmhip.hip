@@ -66,8 +66,19 @@ __device__ __forceinline__ int sigma_tile_dev(const wm::RawTile& raw, float (&s)
 #if !defined(WM_NO_ASM_JACOBI)
   wm::v2f a[4][8];
   float n2[8];
-  // sigma only: test from the 3rd sweep on at cos^2 <= 1e-3 (the values are an order ahead of the vectors), no pair skipping
-  const unsigned long long more = jacobi_cols_gfx950(raw.lo, raw.hi, a, n2, wm::JAC_CONV2_SIGMA, 0.0f, 3, 1 << 20);
+  // sigma only: test from the 3rd sweep on at cos^2 <= 1e-3 (the values are an order ahead of the vectors); from the
+  // same sweep on a pair that is below cos^2 = 1e-8 in every tile of the wave is left alone (a third of the 4th
+  // sweep's pair visits, tools/skip_study.cpp).  The threshold is set by the near-degenerate pairs: a residual
+  // cosine c between two equal singular values moves them by c s_i / 2, so 1e-8 bounds the error at 5e-5 s_i;
+  // 1e-6 measured 4.7e-4 s_1 on one tile of a 4K noise frame (profiles/r02m_sigma_skip.log), 1e-7 and 1e-8 leave
+  // every value of four 4K frames where the full sweeps leave it (5e-6 s_1).
+#ifndef WM_SIGMA_SKIP2
+#define WM_SIGMA_SKIP2 1e-8f
+#endif
+#ifndef WM_SIGMA_SKIP_FROM
+#define WM_SIGMA_SKIP_FROM 2
+#endif
+  const unsigned long long more = jacobi_cols_gfx950(raw.lo, raw.hi, a, n2, wm::JAC_CONV2_SIGMA, WM_SIGMA_SKIP2, 3, WM_SIGMA_SKIP_FROM);
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = wm::fsqrt(n2[i]);
   return more ? -1 : 1;
