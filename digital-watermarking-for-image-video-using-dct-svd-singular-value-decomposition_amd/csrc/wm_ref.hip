@@ -32,7 +32,10 @@ namespace {
 
 constexpr int RB = 32;        // rows per Jacobi block
 constexpr int RP = 2 * RB;    // rows per block pair
-constexpr int GRAM_CC = 128;  // columns per Gram partial
+#ifndef WM_GRAM_CC
+#define WM_GRAM_CC 128
+#endif
+constexpr int GRAM_CC = WM_GRAM_CC;  // columns per Gram partial (128 or 256)
 constexpr int MAX_SWEEPS = 40;
 constexpr int FULL_INNER_SWEEPS = 0;   // outer sweeps whose every step runs the full 63-step inner schedule
 constexpr float CONV_COS = 2e-5f;   // float32 Gram entries resolve cos down to ~eps*sqrt(M)
@@ -186,20 +189,21 @@ __global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, 
   const int2 pr = pairs[p];
   const int c_begin = ch * GRAM_CC;
   {
-    // 64 rows x 128 columns: thread t takes column t & 127 of rows (t >> 7) + 2 i; all 32 loads are
+    // 64 rows x GRAM_CC columns: thread t takes column t % GRAM_CC of rows t / GRAM_CC + RSTEP i; all loads are
     // issued before the LDS stores
-    const int c = t & 127, gc = c_begin + c;
+    constexpr int RSTEP = 256 / GRAM_CC, NLD = RP / RSTEP;
+    const int c = t % GRAM_CC, r0 = t / GRAM_CC, gc = c_begin + c;
     const bool valid = gc < M;
     const int gcc = valid ? gc : M - 1;
-    float v[32];
+    float v[NLD];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int r = (t >> 7) + 2 * i;
+    for (int i = 0; i < NLD; ++i) {
+      const int r = r0 + RSTEP * i;
       const int grow = (r < RB) ? pr.x * RB + r : pr.y * RB + (r - RB);
       v[i] = aug[(size_t)grow * ld + gcc];
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) Xs[(t >> 7) + 2 * i][c] = valid ? v[i] : 0.0f;
+    for (int i = 0; i < NLD; ++i) Xs[r0 + RSTEP * i][c] = valid ? v[i] : 0.0f;
   }
   __syncthreads();
   const int i0 = (wv >> 1) * 32, j0 = (wv & 1) * 32;
@@ -345,6 +349,93 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #if defined(WM_INNER_DIAG)
   st2 = __builtin_amdgcn_s_memtime();
 #endif
+  float* out = Rout + (size_t)p * RP * RP;
+#if defined(WM_INNER_R_LDS)      // A/B only: R through LDS on every step (the round-2a kernel)
+  if (false) {
+#else
+  if (cross_only) {
+#endif
+    // Cross-block schedule (32 steps; every step of a sweep but the first): block-I row k meets block-J row
+    // (k + step) mod 32.  R never touches LDS here: thread (kr, k2) keeps R[r][k2] (its block-I column, fixed) and
+    // R[r][32 + (k2 + step) mod 32] (the block-J column of its current pair) for its rows r = kr + KR j in
+    // registers; after a step the block-J values move one lane down (ds_bpermute, no LDS memory), so that every
+    // lane holds the column of its next partner.  After 32 steps they are back where they started.  This takes
+    // the 8 192 R accesses (half of them ds_write_b32 at 64 B/clk) out of each step's LDS time.
+    float ri[2 * INNER_NB], rj[2 * INNER_NB];
+#pragma unroll
+    for (int j = 0; j < 2 * INNER_NB; ++j) {
+      const int r = kr + INNER_KR * j;
+      ri[j] = (r == k2) ? 1.0f : 0.0f;            // R starts as the identity (the LDS copy is not used on this path)
+      rj[j] = (r == RB + k2) ? 1.0f : 0.0f;
+    }
+    const int shl = ((t & 32) | ((t + 1) & 31)) << 2;     // byte address of the lane one up within the half-wave
+    for (int step = 0; step < RB; ++step) {
+      float (*Gn)[RP + 1] = GG[(step + 1) & 1];
+      const int p2 = k2, q2 = RB + ((k2 + step) & (RB - 1));
+      int q1[INNER_NB];
+#pragma unroll
+      for (int i = 0; i < INNER_NB; ++i) q1[i] = RB + ((kr + INNER_KR * i + step) & (RB - 1));
+      const float app = G[p2][p2], aqq = G[q2][q2], apq = G[p2][q2];
+      float g[INNER_NB][4];
+#pragma unroll
+      for (int i = 0; i < INNER_NB; ++i) {
+        const int p1 = kr + INNER_KR * i;
+        g[i][0] = G[p1][p2]; g[i][1] = G[p1][q2]; g[i][2] = G[q1[i]][p2]; g[i][3] = G[q1[i]][q2];
+      }
+      const float tau = aqq - app, g2 = apq + apq;
+      const float ta = fabsf(tau) + 1e-18f;
+      const float ih = __builtin_amdgcn_rsqf(fmaf(g2, g2, ta * ta));
+      const float x = fmaf(0.5f * ta, ih, 0.5f);
+      const float rx = __builtin_amdgcn_rsqf(x);
+      float c0 = x * rx, s0 = (apq * ih) * rx;
+      const float nrm = fmaf(-0.5f, fmaf(c0, c0, s0 * s0), 1.5f);
+      c0 *= nrm; s0 *= nrm;
+      const bool sw = tau > 0.0f;
+      const float C2 = sw ? s0 : c0, S2 = sw ? -c0 : -s0;
+#pragma unroll
+      for (int i = 0; i < INNER_NB; ++i) {
+        const int p1 = kr + INNER_KR * i;
+        const int la = 2 * wv_s + INNER_KR * i;
+        const float C1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), la));
+        const float C1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), la + 1));
+        const float S1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), la));
+        const float S1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), la + 1));
+        const float C1 = hi ? C1b : C1a, S1 = hi ? S1b : S1a;
+        const float gpp = g[i][0], gpq = g[i][1], gqp = g[i][2], gqq = g[i][3];
+        const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;
+        const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;
+        Gn[p1][p2] = C1 * a0 - S1 * b0; Gn[p1][q2] = C1 * a1 - S1 * b1;
+        Gn[q1[i]][p2] = S1 * a0 + C1 * b0; Gn[q1[i]][q2] = S1 * a1 + C1 * b1;
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * INNER_NB; ++j) {
+        const float rp = ri[j], rq = rj[j];
+        ri[j] = C2 * rp - S2 * rq;
+        const float nq = S2 * rp + C2 * rq;
+        rj[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(shl, __float_as_int(nq)));   // lane k2 takes lane k2 + 1's block-J column
+      }
+      __syncthreads();
+      G = Gn;
+    }
+#if defined(WM_INNER_DIAG)
+    st3 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int j = 0; j < 2 * INNER_NB; ++j) {
+      const int r = kr + INNER_KR * j;
+      out[r * RP + k2] = ri[j];
+      out[r * RP + RB + k2] = rj[j];
+    }
+#if defined(WM_INNER_DIAG)
+    __syncthreads();
+    if (t == 0 && p == 1 && blockIdx.z == 0) {
+      const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+      printf("inner diag (cross, R in registers): load %llu maxcos %llu loop %llu (%llu per step) store %llu cycles\n", st1 - st0,
+             st2 - st1, st3 - st2, (st3 - st2) / 32ull, st4 - st3);
+    }
+#endif
+    return;
+  }
   for (int step = 0; step < n_inner; ++step) {
     float (*Gn)[RP + 1] = GG[(step + 1) & 1];
     // ---- indices of this step's pairs (cross_only: block-I row k with block-J row (k + step) mod 32) ----
@@ -412,7 +503,6 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #if defined(WM_INNER_DIAG)
   st3 = __builtin_amdgcn_s_memtime();
 #endif
-  float* out = Rout + (size_t)p * RP * RP;
   for (int e = t; e < RP * RP; e += INNER_NT) out[e] = R[e >> 6][e & 63];
 #if defined(WM_INNER_DIAG)
   __syncthreads();
@@ -606,6 +696,7 @@ RefPlan make_plan(int H, int W, int B = 1) {
   // plane keeps the small units that fill the chip.
   const int units = p.npairs * B;                       // (pair, plane) items per step
   p.apply_tiles = units >= 96 ? 2 : 1;
+  if (const char* e = getenv("WM_RF_APPLY_TILES")) { const int v = atoi(e); if (v >= 1 && v <= 8) p.apply_tiles = v; }   // tuning knob
   p.nch = (p.M + GRAM_CC - 1) / GRAM_CC;    // Gram stays in many small units: a float4 / double-buffered / 512-column variant measured slower (36-40 vs 31 us)
   return p;
 }
