@@ -94,3 +94,22 @@ def test_bench_starts_its_own_ranks():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
     assert j["value"] > 0 and j["config"]["frames_per_rank"] == 4
     assert "roofline" in j and j["roofline"]["achieved"] > 0
+
+
+def test_bench_fullframe_mode_shards_frames_too():
+    """`bench.py --mode fullframe --gpus 2` (reference semantics, one dense SVD per plane): the same launcher, the
+    same per-rank frame batches and watermark broadcast as the tile mode - two gloo ranks on the one GPU here."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "fullframe", "--gpus", "2", "--backend", "gloo",
+                        "--same-device", "--ff-height", "96", "--ff-width", "160", "--ff-frames", "2", "--steps", "2",
+                        "--warmup", "1", "--cpu-frames", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["frames_per_rank"] == 2 and j["roofline"]["bound"] == "mfma"
