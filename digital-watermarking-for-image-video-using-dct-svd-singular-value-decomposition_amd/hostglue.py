@@ -10,6 +10,7 @@ include/wmhip.h.
 from __future__ import annotations
 
 import hashlib
+import os
 import hmac as _hmac
 import threading
 from collections import OrderedDict
@@ -114,15 +115,21 @@ def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
     box = h >= H and w >= W
     My, Mx = _area_matrix(h, H, box), _area_matrix(w, W, box)
     src = img.astype(np.float64)
-    if src.ndim == 2:
-        out = My @ src @ Mx.T
-    else:   # every channel is resized like a gray image: two small BLAS products each (a 3-operand
-            # einsum walks H*W*h*w*c terms - 70 s for a 64x64 logo on a 1080p cover)
-        out = np.stack([My @ src[..., c] @ Mx.T for c in range(src.shape[2])], axis=-1)
-    out += 0.5                                  # round half up, in place (the planes are tens of MB)
-    np.floor(out, out=out)
-    np.clip(out, 0, 255, out=out)
-    return out.astype(np.uint8)
+    planes = [src] if src.ndim == 2 else [src[..., c] for c in range(src.shape[2])]
+    # every channel is resized like a gray image: two BLAS products, evaluated left to right like the oracle's
+    # (float64 products associate differently otherwise, and box-filter results sit on exact .5 ties often enough
+    # for the last bit to show); a 3-operand einsum walks H*W*h*w*c terms - 70 s for a 64x64 logo on a 1080p cover.
+    # Rounding is half up: floor(x + 0.5), which for the non-negative values of a convex combination of uint8
+    # pixels is what the float64 -> uint8 cast of x + 0.5 does (truncation), so the passes over the H x W
+    # doubles (0.17 s of a 0.23 s embed_arrays at 4K in round 1's five-pass form) are one in-place add and one
+    # narrowing copy into a planar buffer, interleaved at the end.
+    planar = np.empty((len(planes), H, W), np.uint8)
+    for c, p_ in enumerate(planes):
+        t_ = My @ p_ @ Mx.T
+        np.add(t_, 0.5, out=t_)
+        planar[c] = t_                              # assignment truncates like astype (same_kind casting would refuse)
+    out = planar[0] if src.ndim == 2 else np.ascontiguousarray(np.moveaxis(planar, 0, -1))
+    return out
 
 
 # ---- security wrapper (single:59-86) -----------------------------------------
