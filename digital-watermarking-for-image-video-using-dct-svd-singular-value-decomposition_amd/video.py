@@ -102,7 +102,7 @@ def prepare_watermark(ctx: hostapi.Context, wm_bgr: np.ndarray, H: int, W: int, 
     tile=8: per-tile factors; tile=None: the reference's full-plane factors."""
     wm = hg.resize_area(wm_bgr, W, H)
     idx = hg.permutation_index(H, W, key)
-    wy_s = hg.permute(hg.bgr_to_gray(wm).astype(np.float32), idx)
+    wy_s = ctx.permute_planes(hg.bgr_to_gray(wm), idx)                 # single:66-72, index pass on the device
     Uw, Sw, Vwt = ctx.svd_tiles(wy_s) if tile else ctx.ref_svd(wy_s, apply_dct=True)
     return Uw, Sw, Vwt, idx
 
@@ -267,8 +267,7 @@ def extract_watermark_video(stego_video_path: str, metadata_path: str, output_im
         tile = _meta_tile(data)
         K = _k_of(tile, float(data["kfrac"]), int(data["k_floor"]), H, W)
         wy_s = extract_frames_mean(ctx, ys, data["Sc"], data["Uw"], data["Vwt"], float(data["alpha"]), K, batch, tile)
-        wy = hg.unpermute(wy_s, hg.permutation_index(H, W, key))
-        img = ctx.normalize_u8(wy, normalize)
+        img = ctx.unpermute_normalize_u8(wy_s, hg.permutation_index(H, W, key), normalize)   # single:74-80, 221-222 on the device
     finally:
         ctx.close()
     if not output_image_path.lower().endswith(".png"):
