@@ -413,3 +413,17 @@ def test_generated_jacobi_stream_against_the_cpp_form_on_the_gpu(hostapi):
     ctx.close()
     assert np.max(np.abs(sig_a - sig_c2) / np.maximum(sig_c2[..., :1], 1.0)) < 2e-5    # skip threshold 1e-8: bounded at 5e-5 s_i
     assert np.abs(d_a - d_c).max() < 2e-3
+
+
+def test_device_dct_against_the_published_jpeg_example(gpu_ctx):
+    """The device's DCT on an external known answer: the watermark-side kernel (K3) factors dct2(tile) = U diag(S) Vt,
+    so its product must reproduce the JPEG literature's printed coefficients of the worked example
+    (tests/golden/external/jpeg_dct_example.npz) to the two decimals they are printed with."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "external", "jpeg_dct_example.npz"))
+    plane = np.tile(g["block"].astype(np.float32), (2, 3))                 # six copies: a 16 x 24 plane
+    U, S, Vt = gpu_ctx.svd_tiles(plane)
+    for ty in range(2):
+        for tx in range(3):
+            C = (U[ty, tx] * S[ty, tx]) @ Vt[ty, tx]
+            assert np.abs(C - g["dct"]).max() < 6e-3

@@ -44,6 +44,17 @@ def test_dct8x8_matches_closed_form(hh):
     assert np.abs(a - t).max() < 1e-3
 
 
+def test_dct8x8_against_the_published_jpeg_example(hh):
+    """The kernels' 8-point DCT (wm_tile_math.h, CPU build) on the JPEG literature's worked example
+    (tests/golden/external/jpeg_dct_example.npz: an external known answer, two printed decimals)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "external", "jpeg_dct_example.npz"))
+    a = g["block"].astype(np.float32).copy()
+    hh.hh_dct8x8(vp(a), 0)
+    assert np.abs(a - g["dct"]).max() < 6e-3
+    hh.hh_dct8x8(vp(a), 1)
+    assert np.abs(a - g["block"]).max() < 1e-3
+
+
 @pytest.mark.parametrize("variant", ["literal", "packed"])
 @pytest.mark.parametrize("H,W", [(64, 96), (256, 256)])
 def test_embed_tile_math_vs_oracle(hh, variant, H, W):

@@ -162,3 +162,19 @@ def test_oracle_reproduces_golden_fixture(path):
     assert abs(score - float(g["detect_score"])) < 1e-4
     ex = o.extract_arrays(g["stego"], r["meta"], "golden-pw", True, tile, int(g["k_floor"]))
     assert np.mean(np.abs(ex.astype(int) - g["extracted"].astype(int)) > 1) < 1e-2
+
+
+def test_dct_against_the_published_jpeg_worked_example():
+    """An EXTERNAL known answer for the 2-D orthonormal DCT-II (what cv2.dct computes, single:32-33): the 8x8 worked
+    example of the JPEG literature (level-shifted sample block -> DCT coefficients printed to two decimals; e.g. the
+    'JPEG' article of Wikipedia, DC term -415.38), stored in tests/golden/external/jpeg_dct_example.npz.  Not held by the
+    reference (it holds nothing), so parity stays 'unpinned' - but it is a vector neither the oracle nor the kernels
+    produced."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "external", "jpeg_dct_example.npz"))
+    X, C = g["block"], g["dct"]
+    assert abs(C[0, 0] + 415.38) < 1e-9
+    assert np.abs(o.dct2(X.astype(np.float32)) - C).max() < 6e-3          # two printed decimals
+    assert np.abs(o.idct2(o.dct2(X.astype(np.float32))) - X).max() < 1e-3
+    D = o.dct_basis(8)
+    assert np.abs(D @ X @ D.T - C).max() < 6e-3
