@@ -427,3 +427,22 @@ def test_device_dct_against_the_published_jpeg_example(gpu_ctx):
         for tx in range(3):
             C = (U[ty, tx] * S[ty, tx]) @ Vt[ty, tx]
             assert np.abs(C - g["dct"]).max() < 6e-3
+
+
+def test_tile_singular_values_against_a_published_example(gpu_ctx):
+    """External known answer for the tile SVD on the device: the 4 x 5 example of Wikipedia's 'Singular value
+    decomposition' article (singular values 3, sqrt 5, 2, 0) zero-padded to an 8 x 8 uint8 tile, scaled by 1, 17 and 63
+    (so that the values are exact multiples), through the sigma-only kernel and through embed's Sc side output
+    (a rank-3 tile: the fallback path)."""
+    from test_oracle import _wikipedia_svd_tile
+    m, want = _wikipedia_svd_tile()
+    plane = np.zeros((8, 64), np.uint8)
+    scales = [1, 17, 63, 1, 17, 63, 1, 17]
+    for k, sc_ in enumerate(scales):
+        plane[:, 8 * k:8 * k + 8] = m * sc_
+    s = gpu_ctx.sigma_tiles(plane)[0]
+    for k, sc_ in enumerate(scales):
+        assert np.abs(s[k] - want * sc_).max() < 2e-5 * 3 * sc_ + 1e-5, k
+    _, sc, _ = gpu_ctx.embed_tiles(plane, np.zeros((1, 8, 8), np.float32), 0.15)
+    for k, sc_ in enumerate(scales):
+        assert np.abs(sc[0, k] - want * sc_).max() < 2e-4 * 3 * sc_ + 1e-3, k        # completion pattern: 2^-14 added to the DCT tile

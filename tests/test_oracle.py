@@ -178,3 +178,17 @@ def test_dct_against_the_published_jpeg_worked_example():
     assert np.abs(o.idct2(o.dct2(X.astype(np.float32))) - X).max() < 1e-3
     D = o.dct_basis(8)
     assert np.abs(D @ X @ D.T - C).max() < 6e-3
+
+
+def _wikipedia_svd_tile():
+    """The 4 x 5 matrix of Wikipedia's 'Singular value decomposition' article (singular values 3, sqrt(5), 2, 0),
+    zero-padded to an 8 x 8 uint8 tile: an external known answer for the tile SVD."""
+    m = np.zeros((8, 8), np.uint8)
+    m[:4, :5] = [[1, 0, 0, 0, 2], [0, 0, 3, 0, 0], [0, 0, 0, 0, 0], [0, 2, 0, 0, 0]]
+    return m, np.array([3.0, np.sqrt(5.0), 2.0, 0, 0, 0, 0, 0])
+
+
+def test_tile_singular_values_against_a_published_example():
+    m, want = _wikipedia_svd_tile()
+    s = o.stego_sigma(m.astype(np.float32), 8).reshape(-1)
+    assert np.abs(s - want).max() < 1e-5
