@@ -446,3 +446,34 @@ def test_tile_singular_values_against_a_published_example(gpu_ctx):
     _, sc, _ = gpu_ctx.embed_tiles(plane, np.zeros((1, 8, 8), np.float32), 0.15)
     for k, sc_ in enumerate(scales):
         assert np.abs(sc[0, k] - want * sc_).max() < 2e-4 * 3 * sc_ + 1e-3, k        # completion pattern: 2^-14 added to the DCT tile
+
+
+def test_bad_args_of_the_round2_entry_points(gpu_ctx, hostapi):
+    """NULL / out-of-range arguments of the entry points added in round 2 come back as WM_ERR_BADARG (ValueError),
+    never as a launch: raw C ABI."""
+    import ctypes as C
+    lib, h = gpu_ctx.lib, gpu_ctx._h
+    vp = C.c_void_p
+    d = gpu_ctx.malloc(4096)
+    try:
+        for name, args in (
+            ("wm_permute_u8_f32_dev", (None, vp(d), vp(d), 16, 1)),
+            ("wm_permute_f32_dev", (vp(d), vp(d), vp(d), 16, 1)),                      # in place
+            ("wm_unpermute_f32_dev", (vp(d), None, vp(d + 1024), 16, 1)),
+            ("wm_permute_f32_dev", (vp(d), vp(d + 2048), vp(d + 1024), 1 << 31, 1)),    # index is int32
+            ("wm_unpermute_f32_dev", (vp(d), vp(d + 2048), vp(d + 1024), 16, 70000)),
+            ("wm_ref_sigma_planes_u8_dev", (None, vp(d), 1, 8, 8, 8, 64)),
+            ("wm_ref_sigma_planes_u8_dev", (vp(d), vp(d + 1024), 0, 8, 8, 8, 64)),
+            ("wm_ref_embed_planes_u8_dev", (vp(d), vp(d + 1024), vp(d + 2048), None, None, 1, 8, 8, 8, 64, 0, 0.1, 4)),
+            ("wm_ref_embed_planes_u8_dev", (vp(d), vp(d + 1024), vp(d + 2048), vp(d + 3072), None, 1, 8, 8, 8, 64, 0, 0.1, 9)),
+            ("wm_ref_extract_planes_u8_dev", (vp(d), vp(d + 1024), None, vp(d + 2048), vp(d + 3072), 1, 8, 8, 8, 64, 0.1, 4)),
+            ("wm_ref_detect_planes_u8_dev", (vp(d), vp(d + 1024), vp(d + 2048), None, 1, 8, 8, 8, 64, 0.1)),
+            ("wm_ref_sigma_planes_u8_dev", (vp(d), vp(d + 1024), 1, 8, 8, 4, 64)),      # row_stride < W
+        ):
+            rc = getattr(lib, name)(h, *args)
+            assert rc == hostapi.WM_ERR_BADARG, (name, rc, lib.wm_last_error())
+        # zero-sized permute is a no-op
+        assert lib.wm_permute_f32_dev(h, None, None, None, 0, 1) == hostapi.WM_OK
+    finally:
+        gpu_ctx.free(d)
+    gpu_ctx.check_status()
