@@ -626,7 +626,13 @@ WM_HD void jacobi_rot_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], const
 // n2 = |b_i|^2, vn2 = |v_i|^2 (1 up to the drift of v_rsq_f32, carried so that it
 // cancels in sigma_i = |b_i| / |v_i|).  Column norms are recomputed before every
 // sweep: this is the path for tiles whose trailing columns are ~1e-8 of the leading one.
+#if defined(__HIPCC__) && !defined(WM_NO_ASM_JACOBI) && !defined(WM_NO_ASM_JACOBI_V)
+#include "wm_jacobi_v_gfx950.inc"      // generated gfx950 stream of the iteration below (tools/gen_jacobi_asm.py)
+#endif
 WM_HD int jacobi_cols_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], float (&vn2)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WM_NO_ASM_JACOBI) && !defined(WM_NO_ASM_JACOBI_V)
+  return jacobi_cols_v_gfx950(a, v, n2, vn2, JAC_CONV2);
+#else
 #pragma unroll
   for (int rp = 0; rp < 4; ++rp)
 #pragma unroll
@@ -656,6 +662,7 @@ WM_HD int jacobi_cols_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], float
   col_norms2_pk(a, n2);
   col_norms2_pk(v, vn2);
   return more ? -sweep : sweep;
+#endif
 }
 
 // literal chain on a (possibly) rank-deficient tile: dct2 -> (+delta P) -> svd

@@ -394,9 +394,12 @@ def test_generated_jacobi_stream_against_the_cpp_form_on_the_gpu(hostapi):
         (yy + xx) % 2 * 255,
     ]).astype(np.uint8)
     wys = rng.integers(0, 256, (H, W)).astype(np.float32)
-    res = []
+    wys[:64] = 77.0                                 # rank-1 tiles and ...
+    wys[64:128] = ((yy + xx) % 2 * 255)[64:128]     # ... rank-2 tiles on the watermark side too (the stream with V)
+    res, svds = [], []
     for ctx in (hostapi.Context(0), Ctx(lib)):
         U, S, Vt = ctx.svd_tiles(wys)
+        svds.append((U, S, Vt))
         st, sc, _ = ctx.embed_tiles(planes, S, 0.15)
         sig = ctx.sigma_tiles(st)
         w = ctx.extract_tiles(st, sc, U, Vt, 0.15)
@@ -404,6 +407,11 @@ def test_generated_jacobi_stream_against_the_cpp_form_on_the_gpu(hostapi):
         res.append((st, sc, sig, w, d))
         ctx.close()
     (st_a, sc_a, sig_a, w_a, d_a), (st_c, sc_c, sig_c, w_c, d_c) = res
+    (U_a, S_a, Vt_a), (U_c, S_c, Vt_c) = svds
+    assert np.max(np.abs(S_a - S_c) / np.maximum(S_c[..., :1], 1.0)) < 2e-6
+    rec = lambda U_, S_, Vt_: np.einsum("...ri,...i,...ic->...rc", U_, S_, Vt_)
+    assert np.max(np.abs(rec(U_a, S_a, Vt_a) - rec(U_c, S_c, Vt_c))) < 2e-3     # DCT coefficients up to 2040: 1e-6 relative
+    assert np.max(np.abs(np.einsum("...ic,...jc->...ij", Vt_a, Vt_a) - np.eye(8))) < 1e-5
     assert np.max(np.abs(sc_a - sc_c) / np.maximum(sc_c[..., :1], 1.0)) < 2e-6
     dd = np.abs(st_a.astype(int) - st_c.astype(int))
     assert dd.max() <= 1 and np.mean(dd != 0) < 1e-4

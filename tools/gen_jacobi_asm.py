@@ -19,41 +19,56 @@ Same arithmetic as jacobi_rot_pk (two-rsq angle, de Rijk swap, cancellation-free
 skip of a pair that is below the skip threshold in all 64 tiles), same pair order (row-cyclic), same sweep
 control (norms recomputed before odd sweeps, convergence test on cos^2, sweep bound 12).
 
-    python tools/gen_jacobi_asm.py          # rewrites the .inc next to the kernels
+A second stream, csrc/wm_jacobi_v_gfx950.inc (build_v), is jacobi_cols_pk_v: the same rotation applied to the
+stacked rows of B and V (v[40:103], v[104:167]), every pair tested and rotated, a converged lane leaving the
+exec mask - the literal path of rank-deficient tiles and the watermark-side SVD.
+
+    python tools/gen_jacobi_asm.py          # rewrites both .inc files next to the kernels
 """
 import os
 import struct
 import sys
 
-A0 = 40          # B = X V: v2f a[rp][c] at v[A0 + 2 (8 rp + c)], rows (2 rp, 2 rp + 1) in (lo, hi)
-N0 = 104         # n2[c]
-T = 112          # temporaries v112..v127
 MAX_SWEEPS = 12
 
 
-def A(rp, c):
-    b = A0 + 2 * (8 * rp + c)
-    return f"v[{b}:{b + 1}]"
+class Lay:
+    """Register file of one stream: B at v[a0 ..], optionally V at v[v0 ..], norms, 16 temporaries at v[t ..]."""
+
+    def __init__(self, a0, n0, t, v0=None, vn0=None):
+        self.A0, self.N0, self.T, self.V0, self.VN0 = a0, n0, t, v0, vn0
+        pr = lambda k: f"v[{t + k}:{t + k + 1}]"
+        self.GV, self.T1, self.T2, self.CS, self.T3 = pr(0), pr(2), pr(4), pr(6), pr(14)
+        self.GVl, self.GVh, self.C, self.S = f"v{t}", f"v{t + 1}", f"v{t + 6}", f"v{t + 7}"
+        (self.g, self.gg, self.ab, self.tau, self.ta, self.t1, self.ih, self.x) = (f"v{t + k}" for k in range(8, 16))
+
+    def A(self, rp, c, base=None):
+        b = (self.A0 if base is None else base) + 2 * (8 * rp + c)
+        return f"v[{b}:{b + 1}]"
+
+    def V(self, rp, c):
+        return self.A(rp, c, self.V0)
+
+    def Alo(self, rp, c):
+        return f"v{self.A0 + 2 * (8 * rp + c)}"
+
+    def Ahi(self, rp, c):
+        return f"v{self.A0 + 2 * (8 * rp + c) + 1}"
+
+    def N(self, c, base=None):
+        return f"v{(self.N0 if base is None else base) + c}"
 
 
-def Alo(rp, c):
-    return f"v{A0 + 2 * (8 * rp + c)}"
-
-
-def Ahi(rp, c):
-    return f"v{A0 + 2 * (8 * rp + c) + 1}"
-
-
-def N(c):
-    return f"v{N0 + c}"
-
-
-GV, T1, T2, CS, T3 = "v[112:113]", "v[114:115]", "v[116:117]", "v[118:119]", "v[126:127]"
-GVl, GVh, C, S = "v112", "v113", "v118", "v119"
-g, gg, ab, tau, ta, t1, ih, x = "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+# the V-free stream (embed / sigma kernels): B in v[40:103], n2 in v[104:111], temporaries v[112:127]
+LAY = Lay(40, 104, 112)
+A0, N0, T = LAY.A0, LAY.N0, LAY.T
+# the stream with V (fallback embed, watermark-side SVD): B v[40:103], V v[104:167], |b|^2 v[168:175], |v|^2 v[176:183],
+# temporaries v[184:199]
+LAY_V = Lay(40, 168, 184, v0=104, vn0=176)
 # SGPRs (clobbered): mask, sweep counter, constants
 M, SW, EPS, CONV, SKIPC, MINSW, SKIPFROM = "s[80:81]", "s82", "s83", "s84", "s85", "s86", "s87"
 TMPM, NOSKIP, TMPS = "s[88:89]", "s[90:91]", "s92"
+SAVE = "s[88:89]"       # with-V stream: the caller's exec mask (TMPM / NOSKIP are unused there)
 
 
 class Stream:
@@ -109,24 +124,30 @@ class Stream:
         return sum(1 for ln in self.lines if ln.startswith("s_nop"))
 
 
-def col_norms(st):
+def col_norms(st, L=LAY, of_v=False):
     """n2[c] = sum over rows of a[.][c]^2: four independent chains at a time (no packed result is read
-    by the instruction after its producer)."""
-    tmps = [GV, T1, T2, CS]
+    by the instruction after its producer).  of_v: the norms of V's columns into vn2."""
+    tmps = [L.GV, L.T1, L.T2, L.CS]
+    mat = (lambda rp, c: L.V(rp, c)) if of_v else (lambda rp, c: L.A(rp, c))
+    nb = L.VN0 if of_v else L.N0
     for c0 in (0, 4):
         for i in range(4):
-            st.emit(f"v_pk_mul_f32 {tmps[i]}, {A(0, c0 + i)}, {A(0, c0 + i)}")
+            st.emit(f"v_pk_mul_f32 {tmps[i]}, {mat(0, c0 + i)}, {mat(0, c0 + i)}")
         for rp in (1, 2, 3):
             for i in range(4):
-                st.emit(f"v_pk_fma_f32 {tmps[i]}, {A(rp, c0 + i)}, {A(rp, c0 + i)}, {tmps[i]}")
+                st.emit(f"v_pk_fma_f32 {tmps[i]}, {mat(rp, c0 + i)}, {mat(rp, c0 + i)}, {tmps[i]}")
         for i in range(4):
             lo = tmps[i][2:-1].split(":")[0]
-            st.emit(f"v_add_f32_e32 {N(c0 + i)}, v{lo}, v{int(lo) + 1}")
+            st.emit(f"v_add_f32_e32 {L.N(c0 + i, nb)}, v{lo}, v{int(lo) + 1}")
 
 
-def rotation(st, p, q, uid, plain=False):
+def rotation(st, p, q, uid, plain=False, L=LAY, with_v=False):
     """One Jacobi rotation of columns p < q (jacobi_rot_pk<CHECK, SKIP>); plain: no convergence test, no skip
-    (the sweeps that can never be the last one)."""
+    (the sweeps that can never be the last one); with_v: tested, never skipped, V's columns rotated too
+    (jacobi_rot_pk_v<1>)."""
+    A, N = L.A, L.N
+    GV, T1, T2, CS, T3, GVl, GVh, C, S = L.GV, L.T1, L.T2, L.CS, L.T3, L.GVl, L.GVh, L.C, L.S
+    g, gg, ab, tau, ta, t1, ih, x = L.g, L.gg, L.ab, L.tau, L.ta, L.t1, L.ih, L.x
     Np, Nq = N(p), N(q)
     st.emit(f"v_pk_mul_f32 {GV}, {A(0, p)}, {A(0, q)}")
     st.emit(f"v_max_f32_e32 {ab}, {Np}, {Nq}" if plain else f"v_mul_f32_e32 {ab}, {Np}, {Nq}")
@@ -139,6 +160,11 @@ def rotation(st, p, q, uid, plain=False):
     st.emit(f"v_add_f32_e32 {g}, {GVl}, {GVh}")                        # g = a_p . a_q
     if plain:
         st.emit(f"v_mul_f32_e32 {gg}, {g}, {g}")
+    elif with_v:
+        st.emit(f"v_mul_f32_e32 {x}, {CONV}, {ab}")
+        st.emit(f"v_mul_f32_e32 {gg}, {g}, {g}")
+        st.emit(f"v_cmp_gt_f32_e32 vcc, {gg}, {x}")                    # notconv |= g^2 > conv2 al be (active lanes only)
+        st.emit(f"s_or_b64 {M}, {M}, vcc", kind="salu")
     else:
         st.emit(f"v_mul_f32_e32 {x}, {CONV}, {ab}")
         st.emit(f"v_mul_f32_e32 {gg}, {g}, {g}")
@@ -170,28 +196,34 @@ def rotation(st, p, q, uid, plain=False):
     st.emit(f"v_add_f32_e64 {Np}, {ab}, |{gg}|")                       # larger norm grows by |t g|
     st.emit(f"v_sub_f32_e64 {Nq}, {ta}, |{gg}|")
     # columns: a_p <- C a_p + S a_q ; a_q <- C a_q - S a_p   (C, S broadcast from the halves of CS by op_sel)
-    for rp0 in (0, 2):
-        tt = ((T1, T2), (GV, T3))
-        for i in (0, 1):
-            rp = rp0 + i
-            st.emit(f"v_pk_mul_f32 {tt[i][0]}, {CS}, {A(rp, q)} op_sel:[1,0]")
-            st.emit(f"v_pk_mul_f32 {tt[i][1]}, {CS}, {A(rp, p)} op_sel:[1,0]")
-        for i in (0, 1):
-            rp = rp0 + i
-            st.emit(f"v_pk_fma_f32 {A(rp, p)}, {CS}, {A(rp, p)}, {tt[i][0]} op_sel_hi:[0,1,1]")
-            st.emit(f"v_pk_fma_f32 {A(rp, q)}, {CS}, {A(rp, q)}, {tt[i][1]} op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]")
-    if not plain:
+    mats = [L.A] + ([L.V] if with_v else [])
+    for mat in mats:
+        for rp0 in (0, 2):
+            tt = ((T1, T2), (GV, T3))
+            for i in (0, 1):
+                rp = rp0 + i
+                st.emit(f"v_pk_mul_f32 {tt[i][0]}, {CS}, {mat(rp, q)} op_sel:[1,0]")
+                st.emit(f"v_pk_mul_f32 {tt[i][1]}, {CS}, {mat(rp, p)} op_sel:[1,0]")
+            for i in (0, 1):
+                rp = rp0 + i
+                st.emit(f"v_pk_fma_f32 {mat(rp, p)}, {CS}, {mat(rp, p)}, {tt[i][0]} op_sel_hi:[0,1,1]")
+                st.emit(f"v_pk_fma_f32 {mat(rp, q)}, {CS}, {mat(rp, q)}, {tt[i][1]} op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+    if not plain and not with_v:
         st.emit(f".Lwmj_skip_{uid}_%=:", kind="label")
         st.hist.append(("nop", set()))       # a taken branch lands here: nothing before it may be assumed
+
+
+def eps_literal():
+    return struct.unpack("<I", struct.pack("<f", 1e-18))[0]  # keeps 0/0 out; its square (1e-36) is a normal float
 
 
 def build():
     st = Stream()
     e = st.emit
+    Alo, Ahi = LAY.Alo, LAY.Ahi
     # inputs: %[lo0..lo7], %[hi0..hi7] raw row words; %[conv] %[skip] %[minsw] %[skipfrom]
     e(f"s_mov_b32 {SW}, 0", kind="salu")
-    eps_bits = struct.unpack("<I", struct.pack("<f", 1e-18))[0]  # keeps 0/0 out; its square (1e-36) is a normal float
-    e(f"s_mov_b32 {EPS}, 0x{eps_bits:08x}", kind="salu")
+    e(f"s_mov_b32 {EPS}, 0x{eps_literal():08x}", kind="salu")
     e(f"s_mov_b32 {CONV}, %[conv]", kind="salu")
     e(f"s_mov_b32 {SKIPC}, %[skip]", kind="salu")
     e(f"s_mov_b32 {MINSW}, %[minsw]", kind="salu")
@@ -241,7 +273,45 @@ def build():
     return st
 
 
-HEADER = '''// GENERATED by tools/gen_jacobi_asm.py - do not edit.  The packed one-sided Jacobi of the tile kernels
+def build_v():
+    """jacobi_cols_pk_v: B = A V with V accumulated from the identity, norms recomputed before every sweep, every
+    pair tested and rotated; a lane (tile) whose own sweep saw nothing to rotate leaves the exec mask and sits out
+    the sweeps its wave neighbours still need, so its result does not depend on which tiles share the wave."""
+    L = LAY_V
+    st = Stream()
+    e = st.emit
+    e(f"s_mov_b64 {SAVE}, exec", kind="salu")
+    e(f"s_mov_b32 {SW}, 0", kind="salu")
+    e(f"s_mov_b32 {EPS}, 0x{eps_literal():08x}", kind="salu")
+    e(f"s_mov_b32 {CONV}, %[conv]", kind="salu")
+    for rp in range(4):
+        for c in range(8):
+            b = L.V0 + 2 * (8 * rp + c)
+            e(f"v_mov_b32_e32 v{b}, {'1.0' if 2 * rp == c else '0'}")
+            e(f"v_mov_b32_e32 v{b + 1}, {'1.0' if 2 * rp + 1 == c else '0'}")
+    e(".Lwmv_sweep_%=:", kind="label")
+    st.hist.append(("nop", set()))
+    e(f"s_mov_b64 {M}, 0", kind="salu")
+    col_norms(st, L)
+    for p in range(7):
+        for q in range(p + 1, 8):
+            rotation(st, p, q, -1, L=L, with_v=True)
+    e(f"s_add_i32 {SW}, {SW}, 1", kind="salu")
+    e(f"s_and_b64 exec, exec, {M}", kind="salu")              # lanes that rotated something stay (SCC = any left)
+    e("s_cbranch_scc0 .Lwmv_done_%=", kind="salu")
+    e(f"s_cmp_lt_i32 {SW}, {MAX_SWEEPS}", kind="salu")
+    e("s_cbranch_scc1 .Lwmv_sweep_%=", kind="salu")
+    e(".Lwmv_done_%=:", kind="label")
+    st.hist.append(("nop", set()))
+    e(f"s_mov_b64 %[more], exec", kind="salu")                # non-zero only when the sweep bound was hit
+    e(f"s_mov_b32 %[sweeps], {SW}", kind="salu")
+    e(f"s_mov_b64 exec, {SAVE}", kind="salu")
+    col_norms(st, L)
+    col_norms(st, L, of_v=True)
+    return st
+
+
+HEADER = """// GENERATED by tools/gen_jacobi_asm.py - do not edit.  The packed one-sided Jacobi of the tile kernels
 // (raw_to_pk + jacobi_cols_pk + final col_norms2_pk of wm_tile_math.h) as one gfx950 instruction stream with
 // pinned registers: B = X V in v[40:103] (a[rp][c] = v[40 + 2 (8 rp + c)] : rows 2 rp, 2 rp + 1),
 // |b_c|^2 in v[104:111], temporaries v[112:127], control in s[80:92].  {n_inst} instructions, {n_nop} s_nop.
@@ -255,16 +325,35 @@ __device__ __forceinline__ unsigned long long jacobi_cols_gfx950(const uint32_t 
                                                                  const int skip_from) {{
   unsigned long long more;
   asm volatile(
-'''
+"""
+
+HEADER_V = """// GENERATED by tools/gen_jacobi_asm.py - do not edit.  jacobi_cols_pk_v of wm_tile_math.h (one-sided Jacobi WITH V:
+// the fallback embed of rank-deficient tiles and the watermark-side SVD) as one gfx950 instruction stream with pinned
+// registers: B = A V in v[40:103], V in v[104:167] (both [rp][c] -> base + 2 (8 rp + c), rows 2 rp, 2 rp + 1),
+// |b_c|^2 in v[168:175], |v_c|^2 in v[176:183], temporaries v[184:199], control in s[80:89].
+// {n_inst} instructions, {n_nop} s_nop.  Every pair is tested (cos^2 > conv2) and rotated; norms are recomputed
+// before every sweep; a lane whose own sweep rotated nothing leaves the exec mask (restored at the end).
+// Included inside namespace wm.  Returns sweeps, negated when the bound of {max_sw} was hit with lanes still active.
+__device__ __forceinline__ int jacobi_cols_v_gfx950(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], float (&vn2)[8],
+                                                    const float conv2) {{
+  unsigned long long more;
+  int sweeps;
+  asm volatile(
+"""
 
 
-def main():
+def csrc_path(name):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                        "digital-watermarking-for-image-video-using-dct-svd-singular-value-decomposition_amd", "csrc", name)
+
+
+def n_instructions(st):
+    return sum(1 for ln in st.lines if not ln.endswith(":"))
+
+
+def render():
     st = build()
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
-                       "digital-watermarking-for-image-video-using-dct-svd-singular-value-decomposition_amd", "csrc",
-                       "wm_jacobi_gfx950.inc")
-    n_inst = sum(1 for ln in st.lines if not ln.endswith(":"))
-    body = HEADER.format(n_inst=n_inst, n_nop=st.nops(), max_sw=MAX_SWEEPS)
+    body = HEADER.format(n_inst=n_instructions(st), n_nop=st.nops(), max_sw=MAX_SWEEPS)
     for ln in st.lines:
         body += f'      "{ln}\\n\\t"\n'
     outs = []
@@ -281,8 +370,43 @@ def main():
     body += "      : " + ",\n        ".join(outs) + "\n"
     body += "      : " + ",\n        ".join(ins) + "\n"
     body += "      : " + ", ".join(clob) + ");\n  return more;\n}\n"
-    open(out, "w").write(body)
-    print(f"wrote {os.path.normpath(out)}: {n_inst} instructions, {st.nops()} s_nop", file=sys.stderr)
+    return st, body
+
+
+def render_v():
+    L = LAY_V
+    st = build_v()
+    body = HEADER_V.format(n_inst=n_instructions(st), n_nop=st.nops(), max_sw=MAX_SWEEPS)
+    for ln in st.lines:
+        body += f'      "{ln}\\n\\t"\n'
+    outs = []
+    for rp in range(4):
+        for c in range(8):
+            b = L.A0 + 2 * (8 * rp + c)
+            outs.append(f'"+{{v[{b}:{b + 1}]}}"(a[{rp}][{c}])')
+    for rp in range(4):
+        for c in range(8):
+            b = L.V0 + 2 * (8 * rp + c)
+            outs.append(f'"=&{{v[{b}:{b + 1}]}}"(v[{rp}][{c}])')
+    for c in range(8):
+        outs.append(f'"=&{{v{L.N0 + c}}}"(n2[{c}])')
+    for c in range(8):
+        outs.append(f'"=&{{v{L.VN0 + c}}}"(vn2[{c}])')
+    outs += ['[more] "=&s"(more)', '[sweeps] "=&s"(sweeps)']
+    ins = ['[conv] "s"(conv2)']
+    clob = [f'"v{i}"' for i in range(L.T, L.T + 16)] + [f'"s{i}"' for i in range(80, 90)] + ['"vcc"', '"scc"']
+    body += "      : " + ",\n        ".join(outs) + "\n"
+    body += "      : " + ",\n        ".join(ins) + "\n"
+    body += "      : " + ", ".join(clob) + ");\n  return more ? -sweeps : sweeps;\n}\n"
+    return st, body
+
+
+def main():
+    for name, fn in (("wm_jacobi_gfx950.inc", render), ("wm_jacobi_v_gfx950.inc", render_v)):
+        st, body = fn()
+        out = csrc_path(name)
+        open(out, "w").write(body)
+        print(f"wrote {os.path.normpath(out)}: {n_instructions(st)} instructions, {st.nops()} s_nop", file=sys.stderr)
 
 
 if __name__ == "__main__":
