@@ -277,45 +277,63 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   // a rank-deficient plane): their mutual cosines are O(1) noise and must not hold convergence up
   const float fl2 = floor2[blockIdx.z];
   const float* src = partials + (size_t)p * nch * RP * RP;
+  // Sum of the column-chunk partials, as 16-byte loads with up to 16 chunks (128 VGPRs) in flight per thread: the
+  // workgroup is alone on its CU and this phase is pure load latency (8 900 cycles with 32 dwords in flight,
+  // profiles/r02_fullframe_inner.md).  Element e = 4 t + k + 4 INNER_NT i; the chunks are added in index order.
+  constexpr int PER4 = RP * RP / 4 / INNER_NT;
+  constexpr int UN = 16;
+  float4 acc[PER4];
+#pragma unroll
+  for (int i = 0; i < PER4; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   {
-    // sum the column-chunk partials: 32 independent loads in flight
-    constexpr int PER = RP * RP / INNER_NT;
-    constexpr int UN = 32 / PER;
-    float acc[PER];
+    const float4* src4 = reinterpret_cast<const float4*>(src) + t;
+    for (int ch = 0; ch < nch; ch += UN) {
+      float4 v[UN][PER4];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = 0.0f;
-    int ch = 0;
-    for (; ch + UN <= nch; ch += UN) {
-      float v[UN][PER];
+      for (int u = 0; u < UN; ++u) {
+        const int c = min(ch + u, nch - 1);            // past the end: a repeated (cached) load, masked below
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
+        for (int i = 0; i < PER4; ++i) v[u][i] = src4[(size_t)c * (RP * RP / 4) + INNER_NT * i];
+      }
 #pragma unroll
-        for (int i = 0; i < PER; ++i) v[u][i] = src[(size_t)(ch + u) * RP * RP + t + INNER_NT * i];
+      for (int u = 0; u < UN; ++u) {
+        const bool in = ch + u < nch;
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
-#pragma unroll
-        for (int i = 0; i < PER; ++i) acc[i] += v[u][i];
+        for (int i = 0; i < PER4; ++i) {
+          acc[i].x += in ? v[u][i].x : 0.0f; acc[i].y += in ? v[u][i].y : 0.0f;
+          acc[i].z += in ? v[u][i].z : 0.0f; acc[i].w += in ? v[u][i].w : 0.0f;
+        }
+      }
     }
-    for (; ch < nch; ++ch)
 #pragma unroll
-      for (int i = 0; i < PER; ++i) acc[i] += src[(size_t)ch * RP * RP + t + INNER_NT * i];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = t + INNER_NT * i;
-      G[e >> 6][e & 63] = acc[i];
-      R[e >> 6][e & 63] = ((e >> 6) == (e & 63)) ? 1.0f : 0.0f;
+    for (int i = 0; i < PER4; ++i) {
+      const int e = 4 * t + 4 * INNER_NT * i, r = e >> 6, c = e & 63;
+      G[r][c] = acc[i].x; G[r][c + 1] = acc[i].y; G[r][c + 2] = acc[i].z; G[r][c + 3] = acc[i].w;
+      if (!cross_only) {          // the cross-only path keeps R in registers
+        R[r][c] = (r == c) ? 1.0f : 0.0f; R[r][c + 1] = (r == c + 1) ? 1.0f : 0.0f;
+        R[r][c + 2] = (r == c + 2) ? 1.0f : 0.0f; R[r][c + 3] = (r == c + 3) ? 1.0f : 0.0f;
+      }
     }
   }
   __syncthreads();
 #if defined(WM_INNER_DIAG)
   st1 = __builtin_amdgcn_s_memtime();
 #endif
+  // largest cosine between two rows of the pair, from the sums still in registers and the diagonal in LDS
   float mx = 0.0f;
-  for (int e = t; e < RP * RP; e += INNER_NT) {
-    const int r = e >> 6, c = e & 63;
-    if (r != c) {
-      const float grr = G[r][r], gcc = G[c][c];
-      if (grr > fl2 && gcc > fl2) mx = fmaxf(mx, fabsf(G[r][c]) * __builtin_amdgcn_rsqf(grr * gcc));
+  {
+    const int c0 = (4 * t) & 63;
+    float dc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dc[k] = G[c0 + k][c0 + k];
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int r = (4 * t + 4 * INNER_NT * i) >> 6;
+      const float grr = G[r][r];
+      const float av[4] = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r != c0 + k && grr > fl2 && dc[k] > fl2) mx = fmaxf(mx, fabsf(av[k]) * __builtin_amdgcn_rsqf(grr * dc[k]));
     }
   }
 #pragma unroll
@@ -875,7 +893,8 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     WM_HIP(hipStreamSynchronize(ctx->stream));       // fl is a local
   }
   const size_t par_ps = (size_t)p.npairs * p.nch * RP * RP, r_ps = (size_t)p.npairs * RP * RP;
-  auto step = [&](hipStream_t st, int z0, int nz, int s, int part) {
+  auto step = [&](hipStream_t st, int g, int s, int part) {
+    const int z0 = zb[g], nz = zb[g + 1] - zb[g];
     const int2* pr = w.pairs + (size_t)s * p.npairs;
     float* aug = w.aug + (size_t)z0 * p.aug_ps;
     float* par = w.partials + (size_t)z0 * par_ps;
@@ -898,12 +917,12 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     auto q = [&](int g) { return g == 0 ? ctx->stream : ctx->aux_stream[g - 1]; };
     for (int g = 0; g < NQ; ++g) {
       if (g > 0) WM_HIP(hipStreamWaitEvent(q(g), ctx->ev_fork[g - 1], 0));
-      step(q(g), zb[g], zb[g + 1] - zb[g], 0, 1);
+      step(q(g), g, 0, 1);
       if (g + 1 < NQ) WM_HIP(hipEventRecord(ctx->ev_fork[g], q(g)));
     }
-    for (int g = 0; g < NQ; ++g) step(q(g), zb[g], zb[g + 1] - zb[g], 0, 2);
+    for (int g = 0; g < NQ; ++g) step(q(g), g, 0, 2);
     for (int s = 1; s < p.nsteps; ++s)
-      for (int g = 0; g < NQ; ++g) step(q(g), zb[g], zb[g + 1] - zb[g], s, 3);
+      for (int g = 0; g < NQ; ++g) step(q(g), g, s, 3);
     for (int g = 1; g < NQ; ++g) {
       WM_HIP(hipEventRecord(ctx->ev_join[g - 1], q(g)));
       WM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g - 1], 0));
