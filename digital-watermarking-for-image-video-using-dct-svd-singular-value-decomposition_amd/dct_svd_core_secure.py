@@ -76,7 +76,7 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
     _check_tile(tile)
     ctx = _ctx(device)
     H, W = cover.shape[:2]
-    wm = hg.resize_area(wm, W, H)                                          # single:118
+    wm = hg.resize_area_cached(wm, W, H)                                   # single:118
     key = hg.derive_key(password, nonce)                                   # single:119
     idx = hg.permutation_index(H, W, key)
     if tile is None:

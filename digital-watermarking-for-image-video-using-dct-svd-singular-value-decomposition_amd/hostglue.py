@@ -132,6 +132,30 @@ def resize_area(img: np.ndarray, W: int, H: int) -> np.ndarray:
     return out
 
 
+_resize_cache: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
+_resize_lock = threading.Lock()
+_RESIZE_CACHE_ENTRIES = 2
+
+
+def resize_area_cached(img: np.ndarray, W: int, H: int) -> np.ndarray:
+    """resize_area, memoised on the image's content (two entries): a caller that embeds one logo into many covers
+    of one size - the reference's GUI and batch use - pays the two float64 products (0.18 s of a 0.24 s 4K
+    embed_arrays) once.  The result is shared and marked read-only."""
+    key = (hashlib.sha1(np.ascontiguousarray(img).tobytes()).digest(), img.shape, str(img.dtype), int(W), int(H))
+    with _resize_lock:
+        hit = _resize_cache.get(key)
+        if hit is not None:
+            _resize_cache.move_to_end(key)
+            return hit
+    out = resize_area(img, W, H)
+    out.setflags(write=False)
+    with _resize_lock:
+        _resize_cache[key] = out
+        while len(_resize_cache) > _RESIZE_CACHE_ENTRIES:
+            _resize_cache.popitem(last=False)
+    return out
+
+
 # ---- security wrapper (single:59-86) -----------------------------------------
 def derive_key(password: str, nonce: bytes) -> bytes:
     return hashlib.sha256(password.encode("utf-8") + nonce).digest()

@@ -100,3 +100,18 @@ def test_read_image_modes(tmp_path):
         got = hg.read_image_bgr(p)
         assert got.dtype == np.uint8 and got.shape == (12, 18, 3) and got.flags.c_contiguous, name
         assert np.array_equal(got, want), name
+
+
+def test_resize_cache_returns_the_same_pixels_and_tracks_content():
+    """resize_area_cached is resize_area memoised on the image's bytes: equal pixels, a changed logo is a miss,
+    and the shared result cannot be written through."""
+    rng = np.random.default_rng(5)
+    wm = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    a = hg.resize_area_cached(wm, 100, 60)
+    assert np.array_equal(a, hg.resize_area(wm, 100, 60))
+    assert hg.resize_area_cached(wm.copy(), 100, 60) is a            # same content: a hit
+    wm2 = wm.copy(); wm2[3, 4, 1] ^= 1
+    b = hg.resize_area_cached(wm2, 100, 60)
+    assert b is not a and np.array_equal(b, hg.resize_area(wm2, 100, 60))
+    assert not a.flags.writeable
+    assert np.array_equal(hg.resize_area_cached(wm, 60, 100), hg.resize_area(wm, 60, 100))   # other size: its own entry
