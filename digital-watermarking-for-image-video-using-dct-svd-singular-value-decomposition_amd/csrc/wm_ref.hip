@@ -169,7 +169,8 @@ __global__ void k_rf_load(const T* __restrict__ src, const size_t src_stride, co
 
 // ---------------------------------------------------------------------------
 // Gram partials: for pair p = (I, J) and column chunk ch,
-//   partial[p][ch][r][c] = sum_{k in chunk} X[r][k] X[c][k],  X = rows of blocks I,J
+//   G[r][c] = sum_{k in chunk} X[r][k] X[c][k],  X = rows of blocks I,J; stored as the three quadrants
+//   partial[p][ch] = [G_II | G_IJ | G_JJ] (32 x 32 each) - G_JI is the transpose (k_rf_inner mirrors it)
 // ---------------------------------------------------------------------------
 // MFMA form: the 64 x 128 chunk of X is staged row-major in LDS (pitch 129: the operand reads
 // X[i0 + lane%32][k + lane/32] of a wave hit 32 distinct banks twice), wave w owns the 32 x 32
@@ -177,6 +178,7 @@ __global__ void k_rf_load(const T* __restrict__ src, const size_t src_stride, co
 // operands both come from X (D = X_I X_J^T).
 typedef float v16f_g __attribute__((ext_vector_type(16)));
 constexpr int GP = GRAM_CC + 1;
+constexpr int GRAM_PART = 3 * RB * RB;      // floats per (pair, chunk) partial: the quadrants (I,I), (I,J), (J,J)
 
 __global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, const size_t aug_plane_stride,
                                                 const int ld, const int M, const int2* __restrict__ pairs,
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, 
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, j = lane & 31, h = lane >> 5;
   const int p = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
   aug += (size_t)blockIdx.z * aug_plane_stride;
-  partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
+  partials += (size_t)blockIdx.z * gridDim.x * nch * GRAM_PART;
   const int2 pr = pairs[p];
   const int c_begin = ch * GRAM_CC;
   {
@@ -206,6 +208,9 @@ __global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, 
     for (int i = 0; i < NLD; ++i) Xs[r0 + RSTEP * i][c] = valid ? v[i] : 0.0f;
   }
   __syncthreads();
+  // G is symmetric: the quadrant (J, I) is the transpose of (I, J) and is neither computed nor stored - a partial
+  // is [Q_II | Q_IJ | Q_JJ], 3 x 32 x 32 floats (GRAM_PART); wave 2 has nothing to do after the staging
+  if (wv == 2) return;
   const int i0 = (wv >> 1) * 32, j0 = (wv & 1) * 32;
   const float* ra = &Xs[i0 + j][h];
   const float* rb = &Xs[j0 + j][h];
@@ -213,11 +218,11 @@ __global__ __launch_bounds__(256) void k_rf_gram(const float* __restrict__ aug, 
 #pragma unroll 16
   for (int kk = 0; kk < GRAM_CC / 2; ++kk)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk], rb[2 * kk], acc, 0, 0, 0);
-  float* out = partials + ((size_t)p * nch + ch) * RP * RP;
+  float* out = partials + ((size_t)p * nch + ch) * GRAM_PART + (wv == 3 ? 2 : wv) * (RB * RB);
 #pragma unroll
   for (int v = 0; v < 16; ++v) {
-    const int row = i0 + 8 * (v / 4) + 4 * h + (v % 4);
-    out[row * RP + j0 + j] = acc[v];
+    const int row = 8 * (v / 4) + 4 * h + (v % 4);
+    out[row * RB + j] = acc[v];
   }
 }
 
@@ -270,30 +275,32 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #if defined(WM_INNER_DIAG)     // diagnostic build only (tools/): where one inner solve spends its cycles
   unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, st3 = 0;
 #endif
-  partials += (size_t)blockIdx.z * gridDim.x * nch * RP * RP;
+  partials += (size_t)blockIdx.z * gridDim.x * nch * GRAM_PART;
   Rout += (size_t)blockIdx.z * gridDim.x * RP * RP;
   maxcos_bits += blockIdx.z;
   // rows whose squared norm is below this plane's floor are numerically null (rounding residue of
   // a rank-deficient plane): their mutual cosines are O(1) noise and must not hold convergence up
   const float fl2 = floor2[blockIdx.z];
-  const float* src = partials + (size_t)p * nch * RP * RP;
+  const float* src = partials + (size_t)p * nch * GRAM_PART;
   // Sum of the column-chunk partials, as 16-byte loads with up to 16 chunks (128 VGPRs) in flight per thread: the
-  // workgroup is alone on its CU and this phase is pure load latency (8 900 cycles with 32 dwords in flight,
-  // profiles/r02_fullframe_inner.md).  Element e = 4 t + k + 4 INNER_NT i; the chunks are added in index order.
-  constexpr int PER4 = RP * RP / 4 / INNER_NT;
+  // workgroup is alone on its CU and this phase is one CU's fetch rate (profiles/r02_fullframe_inner.md).
+  // A partial holds the quadrants (I,I), (I,J), (J,J) (k_rf_gram): float4 f = t + INNER_NT i < 768 is quadrant f >> 8,
+  // row (f & 255) >> 3, columns 4 (f & 7) ..; the chunks are added in index order.
+  constexpr int NF4 = GRAM_PART / 4;
+  constexpr int PER4 = (NF4 + INNER_NT - 1) / INNER_NT;
   constexpr int UN = 16;
   float4 acc[PER4];
 #pragma unroll
   for (int i = 0; i < PER4; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   {
-    const float4* src4 = reinterpret_cast<const float4*>(src) + t;
+    const float4* src4 = reinterpret_cast<const float4*>(src);
     for (int ch = 0; ch < nch; ch += UN) {
       float4 v[UN][PER4];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int c = min(ch + u, nch - 1);            // past the end: a repeated (cached) load, masked below
 #pragma unroll
-        for (int i = 0; i < PER4; ++i) v[u][i] = src4[(size_t)c * (RP * RP / 4) + INNER_NT * i];
+        for (int i = 0; i < PER4; ++i) v[u][i] = src4[(size_t)c * NF4 + min(t + INNER_NT * i, NF4 - 1)];
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -307,11 +314,19 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
     }
 #pragma unroll
     for (int i = 0; i < PER4; ++i) {
-      const int e = 4 * t + 4 * INNER_NT * i, r = e >> 6, c = e & 63;
-      G[r][c] = acc[i].x; G[r][c + 1] = acc[i].y; G[r][c + 2] = acc[i].z; G[r][c + 3] = acc[i].w;
-      if (!cross_only) {          // the cross-only path keeps R in registers
-        R[r][c] = (r == c) ? 1.0f : 0.0f; R[r][c + 1] = (r == c + 1) ? 1.0f : 0.0f;
-        R[r][c + 2] = (r == c + 2) ? 1.0f : 0.0f; R[r][c + 3] = (r == c + 3) ? 1.0f : 0.0f;
+      const int f = t + INNER_NT * i;
+      if (f < NF4) {
+        const int qd = f >> 8, r = ((f & 255) >> 3) + (qd == 2 ? RB : 0), c = 4 * (f & 7) + (qd >= 1 ? RB : 0);
+        const float av[4] = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          G[r][c + k] = av[k];
+          if (qd == 1) G[c + k][r] = av[k];           // the (J, I) quadrant is the transpose
+          if (!cross_only) {                          // the cross-only path keeps R in registers
+            R[r][c + k] = (r == c + k) ? 1.0f : 0.0f;
+            if (qd == 1) R[c + k][r] = 0.0f;
+          }
+        }
       }
     }
   }
@@ -321,19 +336,18 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #endif
   // largest cosine between two rows of the pair, from the sums still in registers and the diagonal in LDS
   float mx = 0.0f;
-  {
-    const int c0 = (4 * t) & 63;
-    float dc[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dc[k] = G[c0 + k][c0 + k];
-#pragma unroll
-    for (int i = 0; i < PER4; ++i) {
-      const int r = (4 * t + 4 * INNER_NT * i) >> 6;
+  for (int i = 0; i < PER4; ++i) {
+    const int f = t + INNER_NT * i;
+    if (f < NF4) {
+      const int qd = f >> 8, r = ((f & 255) >> 3) + (qd == 2 ? RB : 0), c = 4 * (f & 7) + (qd >= 1 ? RB : 0);
       const float grr = G[r][r];
       const float av[4] = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (r != c0 + k && grr > fl2 && dc[k] > fl2) mx = fmaxf(mx, fabsf(av[k]) * __builtin_amdgcn_rsqf(grr * dc[k]));
+      for (int k = 0; k < 4; ++k) {
+        const float gcc = G[c + k][c + k];
+        if (r != c + k && grr > fl2 && gcc > fl2) mx = fmaxf(mx, fabsf(av[k]) * __builtin_amdgcn_rsqf(grr * gcc));
+      }
     }
   }
 #pragma unroll
@@ -771,7 +785,7 @@ int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, 
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += a256(bytes); return o; };
   const size_t B = (size_t)p.B;
-  const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * RP * RP * 4),
+  const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * GRAM_PART * 4),
                o_R = take(B * p.npairs * RP * RP * 4),
                o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_skip = take(B * p.npairs * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
                o_d = take(B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
@@ -892,7 +906,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     WM_HIP(hipMemcpyAsync(w.floor2, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));       // fl is a local
   }
-  const size_t par_ps = (size_t)p.npairs * p.nch * RP * RP, r_ps = (size_t)p.npairs * RP * RP;
+  const size_t par_ps = (size_t)p.npairs * p.nch * GRAM_PART, r_ps = (size_t)p.npairs * RP * RP;
   auto step = [&](hipStream_t st, int g, int s, int part) {
     const int z0 = zb[g], nz = zb[g + 1] - zb[g];
     const int2* pr = w.pairs + (size_t)s * p.npairs;
