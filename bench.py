@@ -266,7 +266,8 @@ def fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup,
     if rank != 0:
         return None
     Lp = (L + 63) // 64 * 64; M = max(H, W); nbk = Lp // 32
-    flops_sweep = (nbk - 1) * (nbk // 2) * (2.0 * 64 * 64 * M + 2.0 * 64 * 64 * M)   # gram + apply GEMM tiles of one sweep
+    # GEMM tiles of one sweep: the Gram kernel computes three of the four 32 x 32 quadrants (G is symmetric), the apply all of R^T X
+    flops_sweep = (nbk - 1) * (nbk // 2) * (2.0 * 3 * 32 * 32 * M + 2.0 * 64 * 64 * M)
     achieved = flops_sweep * sweeps_e * F / t_embed / 1e12
     out = {"metric": "frames/sec embed+extract, full-frame (reference semantics) Y plane",
            "value": world * F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup,
@@ -277,7 +278,7 @@ def fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup,
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                         "kernel": "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)",
-                        "note": f"{sweeps_e} sweeps x {nbk - 1} steps; gram + apply flops only, over the whole embed call "
+                        "note": f"{sweeps_e} sweeps x {nbk - 1} steps; gram (3 quadrants) + apply flops only, over the whole embed call "
                                 f"(the per-pair inner solve and the finalisation GEMMs are in the time, not in the flops)"}}
     if cpu_sample:
         from oracle import wm_oracle as o
