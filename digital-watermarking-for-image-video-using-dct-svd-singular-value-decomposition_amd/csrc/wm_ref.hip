@@ -407,6 +407,9 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
       int q1[INNER_NB];
 #pragma unroll
       for (int i = 0; i < INNER_NB; ++i) q1[i] = RB + ((kr + INNER_KR * i + step) & (RB - 1));
+#if defined(WM_INNER_DIAG)
+      const unsigned long long d0 = __builtin_amdgcn_s_memtime();
+#endif
       const float app = G[p2][p2], aqq = G[q2][q2], apq = G[p2][q2];
       float g[INNER_NB][4];
 #pragma unroll
@@ -414,6 +417,10 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
         const int p1 = kr + INNER_KR * i;
         g[i][0] = G[p1][p2]; g[i][1] = G[p1][q2]; g[i][2] = G[q1[i]][p2]; g[i][3] = G[q1[i]][q2];
       }
+#if defined(WM_INNER_DIAG)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long d1 = __builtin_amdgcn_s_memtime();
+#endif
       const float tau = aqq - app, g2 = apq + apq;
       const float ta = fabsf(tau) + 1e-18f;
       const float ih = __builtin_amdgcn_rsqf(fmaf(g2, g2, ta * ta));
@@ -446,7 +453,17 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
         const float nq = S2 * rp + C2 * rq;
         rj[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(shl, __float_as_int(nq)));   // lane k2 takes lane k2 + 1's block-J column
       }
+#if defined(WM_INNER_DIAG)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long d2 = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+#if defined(WM_INNER_DIAG)
+      if (step == 7 && t == 0 && p == 1 && blockIdx.z == 0) {
+        const unsigned long long d3 = __builtin_amdgcn_s_memtime();
+        printf("inner step diag: reads %llu  angle+update+writes+bpermute %llu  barrier %llu cycles\n", d1 - d0, d2 - d1, d3 - d2);
+      }
+#endif
       G = Gn;
     }
 #if defined(WM_INNER_DIAG)
