@@ -703,8 +703,8 @@ __global__ void k_rf_gather_rows(const float* __restrict__ src, const int ld, co
 
 // deterministic pseudo-random pattern in (-1, 1): the start vectors of the null-space completion
 // (rank-deficient planes); element (r, c) of the matrix with seed `seed`
-__global__ void k_rf_pattern(float* __restrict__ dst, const int rows, const int cols, const unsigned seed) {
-  const int r = blockIdx.y;
+__global__ void k_rf_pattern(float* __restrict__ dst, const int cols, const unsigned seed) {
+  const int r = blockIdx.y;          // grid.y = rows
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
     unsigned h = (unsigned)r * 0x9E3779B1u ^ ((unsigned)c + seed) * 0x85EBCA77u;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
@@ -1140,11 +1140,10 @@ int ref_complete_plane(wm_ctx* ctx, const RefPlan& p, const RefWs& w, int z, con
     gv[i] = (valid[i] && b2[i] > 0.0) ? (float)(1.0 / b2[i]) : 0.0f;
     gu[i] = (valid[i] && tnorm2[i] > 0.0) ? (float)(1.0 / tnorm2[i]) : 0.0f;
   }
-  hipLaunchKernelGGL(k_rf_pattern, dim3(8, n), dim3(256), 0, ctx->stream, Zv, n, p.M, 0x1234567u);
-  hipLaunchKernelGGL(k_rf_pattern, dim3(8, n), dim3(256), 0, ctx->stream, Zu, n, p.L, 0x7654321u);
+  hipLaunchKernelGGL(k_rf_pattern, dim3(8, n), dim3(256), 0, ctx->stream, Zv, p.M, 0x1234567u);
+  hipLaunchKernelGGL(k_rf_pattern, dim3(8, n), dim3(256), 0, ctx->stream, Zu, p.L, 0x7654321u);
   for (int side = 0; side < 2; ++side) {
     float* Z = side == 0 ? Zv : Zu;
-    const int len = side == 0 ? p.M : p.L;
     WM_HIP(hipMemcpyAsync(coef, (side == 0 ? gv : gu).data(), (size_t)p.Lp * 4, hipMemcpyHostToDevice, ctx->stream));
     for (int pass = 0; pass < 2; ++pass) {          // project twice: classical Gram-Schmidt loses digits once
       if (side == 0) WM_TRY(sgemm(ctx, false, true, n, p.Lp, p.M, 1.0f, Z, p.M, Bz, p.ld, 0.0f, C, p.Lp));       // Z B^T
