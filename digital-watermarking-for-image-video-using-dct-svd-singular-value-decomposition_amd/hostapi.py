@@ -549,6 +549,8 @@ class Context:
                 return d
         if idx.size > 0x7fffffff:
             raise ValueError("plane too large for an int32 index")
+        if idx.size and (int(idx.min()) < 0 or int(idx.max()) >= idx.size):
+            raise ValueError("index entries must lie in [0, n)")      # the device passes gather / scatter through it unchecked
         i32 = np.ascontiguousarray(idx, dtype=np.int32)
         d = self.malloc(max(i32.nbytes, 4))
         self.h2d(d, i32)

@@ -94,6 +94,15 @@ def test_meta_shapes_are_validated_before_the_c_abi(hostapi):
         ctx.extract_tiles(st, sc_t, U, U[:, :5], 0.1)
     with pytest.raises(ValueError):
         ctx.reconstruct_tiles(U, np.zeros((nby, nbx, 4), np.float32), U, 64, 96)
+    # the scramble index is gathered / scattered through unchecked on the device: range-checked before the upload
+    bad = np.arange(64 * 96); bad[7] = 64 * 96
+    with pytest.raises(ValueError):
+        ctx.permute_planes(st, bad)
+    bad[7] = -1
+    with pytest.raises(ValueError):
+        ctx.permute_planes(st, bad)
+    with pytest.raises(ValueError):
+        ctx.permute_planes(st, np.arange(64 * 96 - 1))
 
 
 def test_meta_tile_and_stego_size_are_checked():
