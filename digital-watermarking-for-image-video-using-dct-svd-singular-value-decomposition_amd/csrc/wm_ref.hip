@@ -401,21 +401,35 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
       rj[j] = (r == RB + k2) ? 1.0f : 0.0f;
     }
     const int shl = ((t & 32) | ((t + 1) & 31)) << 2;     // byte address of the lane one up within the half-wave
-    for (int step = 0; step < RB; ++step) {
-      float (*Gn)[RP + 1] = GG[(step + 1) & 1];
-      const int p2 = k2, q2 = RB + ((k2 + step) & (RB - 1));
-      int q1[INNER_NB];
+    // The LDS offsets of the moving (block-J) row and column are carried from step to step (add + wrap) instead of
+    // rebuilt from (k + step) mod 32, and the two G buffers are compile-time bases (two steps per loop iteration): the
+    // address arithmetic in front of a step's reads goes from ~35 to ~12 instructions (reads phase 490 -> 360 cycles).
+    // A row pair's rotation comes by v_readlane from the lane that computed it; fetching it by ds_bpermute instead
+    // saves 16 more instructions and is SLOWER (its latency sits in the step's dependent chain; 8 planes 107 -> 101).
+    constexpr int PITCH = RP + 1;
+    float* const gbuf0 = &GG[0][0][0];
+    float* const gbuf1 = &GG[1][0][0];
+    const int dp = k2 * (PITCH + 1);                       // G[p2][p2]
+    int cq = RB + k2;                                      // column q2 of this step's pair
+    int dq = cq * (PITCH + 1);                             // G[q2][q2]
+    int rp_[INNER_NB], rq_[INNER_NB];
 #pragma unroll
-      for (int i = 0; i < INNER_NB; ++i) q1[i] = RB + ((kr + INNER_KR * i + step) & (RB - 1));
+    for (int i = 0; i < INNER_NB; ++i) {
+      rp_[i] = (kr + INNER_KR * i) * PITCH;                // row p1 (fixed)
+      rq_[i] = (RB + kr + INNER_KR * i) * PITCH;           // row q1 (moves one row down per step, wraps to row 32)
+    }
+#if defined(WM_INNER_DIAG)
+    int diag_step = 0;
+#endif
+    auto one_step = [&](const float* __restrict__ Gs, float* __restrict__ Gd) {
 #if defined(WM_INNER_DIAG)
       const unsigned long long d0 = __builtin_amdgcn_s_memtime();
 #endif
-      const float app = G[p2][p2], aqq = G[q2][q2], apq = G[p2][q2];
+      const float app = Gs[dp], aqq = Gs[dq], apq = Gs[k2 * PITCH + cq];
       float g[INNER_NB][4];
 #pragma unroll
       for (int i = 0; i < INNER_NB; ++i) {
-        const int p1 = kr + INNER_KR * i;
-        g[i][0] = G[p1][p2]; g[i][1] = G[p1][q2]; g[i][2] = G[q1[i]][p2]; g[i][3] = G[q1[i]][q2];
+        g[i][0] = Gs[rp_[i] + k2]; g[i][1] = Gs[rp_[i] + cq]; g[i][2] = Gs[rq_[i] + k2]; g[i][3] = Gs[rq_[i] + cq];
       }
 #if defined(WM_INNER_DIAG)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -433,8 +447,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
       const float C2 = sw ? s0 : c0, S2 = sw ? -c0 : -s0;
 #pragma unroll
       for (int i = 0; i < INNER_NB; ++i) {
-        const int p1 = kr + INNER_KR * i;
-        const int la = 2 * wv_s + INNER_KR * i;
+        const int la = 2 * wv_s + INNER_KR * i;            // the lanes that hold the row pairs' rotations (wave-uniform)
         const float C1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), la));
         const float C1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), la + 1));
         const float S1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), la));
@@ -443,8 +456,8 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
         const float gpp = g[i][0], gpq = g[i][1], gqp = g[i][2], gqq = g[i][3];
         const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;
         const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;
-        Gn[p1][p2] = C1 * a0 - S1 * b0; Gn[p1][q2] = C1 * a1 - S1 * b1;
-        Gn[q1[i]][p2] = S1 * a0 + C1 * b0; Gn[q1[i]][q2] = S1 * a1 + C1 * b1;
+        Gd[rp_[i] + k2] = C1 * a0 - S1 * b0; Gd[rp_[i] + cq] = C1 * a1 - S1 * b1;
+        Gd[rq_[i] + k2] = S1 * a0 + C1 * b0; Gd[rq_[i] + cq] = S1 * a1 + C1 * b1;
       }
 #pragma unroll
       for (int j = 0; j < 2 * INNER_NB; ++j) {
@@ -453,18 +466,27 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
         const float nq = S2 * rp + C2 * rq;
         rj[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(shl, __float_as_int(nq)));   // lane k2 takes lane k2 + 1's block-J column
       }
+      // next step: column q2 and the rows q1 move on by one, from 63 back to 32
+      const bool wc = cq == RP - 1;
+      cq = wc ? RB : cq + 1;
+      dq = wc ? RB * (PITCH + 1) : dq + (PITCH + 1);
+#pragma unroll
+      for (int i = 0; i < INNER_NB; ++i) rq_[i] = (rq_[i] == (RP - 1) * PITCH) ? RB * PITCH : rq_[i] + PITCH;
 #if defined(WM_INNER_DIAG)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const unsigned long long d2 = __builtin_amdgcn_s_memtime();
 #endif
       __syncthreads();
 #if defined(WM_INNER_DIAG)
-      if (step == 7 && t == 0 && p == 1 && blockIdx.z == 0) {
+      if (diag_step++ == 7 && t == 0 && p == 1 && blockIdx.z == 0) {
         const unsigned long long d3 = __builtin_amdgcn_s_memtime();
         printf("inner step diag: reads %llu  angle+update+writes+bpermute %llu  barrier %llu cycles\n", d1 - d0, d2 - d1, d3 - d2);
       }
 #endif
-      G = Gn;
+    };
+    for (int it = 0; it < RB / 2; ++it) {      // G starts in buffer 0 and is back there after an even number of steps
+      one_step(gbuf0, gbuf1);
+      one_step(gbuf1, gbuf0);
     }
 #if defined(WM_INNER_DIAG)
     st3 = __builtin_amdgcn_s_memtime();
