@@ -33,7 +33,7 @@ struct wm_ctx {
   int n_cu = 256;                 // multiProcessorCount of the device (persistent grids are sized from it)
   hipStream_t stream = nullptr;
   bool owns_stream = false;
-  int* d_status = nullptr;        // [0] sticky kernel status, [1] embed fallback count
+  int* d_status = nullptr;        // [0] sticky kernel status, [1] embed literal-fallback count, [2] constant-tile count
   void* scratch = nullptr;        // grow-only device scratch (host-pointer wrappers)
   size_t scratch_bytes = 0;
   void* partials = nullptr;       // grow-only detect partial sums

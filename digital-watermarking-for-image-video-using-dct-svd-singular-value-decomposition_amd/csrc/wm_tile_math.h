@@ -575,6 +575,77 @@ constexpr float COMPLETION_PATTERN[8][8] = {
   {+0.385623f, -0.252198f, +0.255703f, +0.219000f, -0.437414f, -0.709251f, -0.041911f, -0.468894f},
   {+0.789973f, +0.864080f, -0.920759f, -0.063243f, +0.524377f, -0.040678f, +0.003126f, -0.226323f}};
 
+#include "wm_completion_tables.inc"     // CONST_TILE_S / CONST_TILE_M (tools/gen_completion_tables.py)
+
+// ---- constant tiles (letterbox bars, flat backgrounds): the literal chain in closed form -------------
+// Every pixel = v: dct2 is 8 v E00, and to first order in delta / (8 v) the SVD of 8 v E00 + delta P is the
+// pattern's own (v = 0) or e0 followed by that of P[1:, 1:] (v > 0) - fixed vectors, so the chain
+// "+ delta P -> svd -> U diag(S + alpha Sw) V^T -> - delta P -> idct2" is  v + alpha sum_i sw_i M_i  with the tabulated
+// pixel-domain matrices M_i, and Sc = (8 v, 0, ..) + delta * (tabulated values).  Same completion as
+// embed_tile_completed (which such a tile would otherwise go through, at ~40 k instructions per wave) to
+// ~1e-2 grey levels; a constant tile takes THIS path whatever shares its wave, so results stay reproducible.
+WM_HD bool raw_is_constant(const RawTile& t) {
+  const uint32_t w = (t.lo[0] & 0xffu) * 0x01010101u;
+  uint32_t diff = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) diff |= (t.lo[r] ^ w) | (t.hi[r] ^ w);
+  return diff == 0;
+}
+WM_HD bool tile_is_constant(const float (&a)[8][8]) {
+  bool same = true;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) same = same && (a[r][c] == a[0][0]);
+  return same;
+}
+// out <- Yw of the constant tile of value v; sc <- its (completed) singular values
+WM_HD void embed_tile_constant(const float v, const float (&sw)[8], const float (&alpha_k)[8], float (&sc)[8],
+                               float (&out)[8][8]) {
+  const bool black = v == 0.0f;
+  float w0[8], w1[8];                       // weights of the v == 0 / v > 0 tables: one of the two sets is zero
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float w = alpha_k[i] * sw[i];
+    w0[i] = black ? w : 0.0f;
+    w1[i] = black ? 0.0f : w;
+    sc[i] = black ? CONST_TILE_S[0][i] : CONST_TILE_S[1][i];
+  }
+  sc[0] = ffma(8.0f, v, sc[0]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = ffma(w0[i], CONST_TILE_M[0][i][r][c], ffma(w1[i], CONST_TILE_M[1][i][r][c], acc));
+      out[r][c] = acc;
+    }
+}
+
+// the same with the table known at compile time (a wave whose constant tiles are all black, or none of them):
+// bit-identical to embed_tile_constant, whose other table only ever adds 0 * M
+template <int TABLE>
+WM_HD void embed_tile_constant_t(const float v, const float (&sw)[8], const float (&alpha_k)[8], float (&sc)[8],
+                                 float (&out)[8][8]) {
+  float w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    w[i] = alpha_k[i] * sw[i];
+    sc[i] = CONST_TILE_S[TABLE][i];
+  }
+  sc[0] = ffma(8.0f, v, sc[0]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = ffma(w[i], CONST_TILE_M[TABLE][i][r][c], acc);
+      out[r][c] = acc;
+    }
+}
+
 WM_HD void add_completion(float (&a)[8][8], const float scale) {
 #pragma unroll
   for (int r = 0; r < 8; ++r)

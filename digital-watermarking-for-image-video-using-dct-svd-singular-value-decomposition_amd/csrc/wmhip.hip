@@ -285,16 +285,41 @@ __device__ __forceinline__ void embed_group(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom& g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status, uint32_t* __restrict__ fb_list,
+    int* __restrict__ status, uint32_t* __restrict__ fb_list, const uint32_t fb_last,
     const int t, const int ty, const int tx, const size_t plane) {
   const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
 
+  // deficient tiles are appended (wave-aggregated) to one of the two fallback lists that share fb_list: the tiles for
+  // the literal chain grow from its front (count status[1]), the constant ones from its back (count status[2])
+  auto append_deficient = [&](const bool flag, const int which) {
+    const unsigned long long dmask = __builtin_amdgcn_ballot_w64(flag);
+    if (dmask == 0ull) return;
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned leader = (unsigned)__builtin_ctzll(dmask);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(status + 1 + which, (int)__builtin_popcountll(dmask));
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (flag) {
+      const unsigned rank = (unsigned)__builtin_popcountll(dmask & ((1ull << lane) - 1ull));
+      const uint32_t slot = base + rank;
+      fb_list[which ? fb_last - slot : slot] = (uint32_t)(plane * g.n_tiles + t);
+    }
+  };
   wm::v2f a[4][8];
   float n2[8];
   int sweeps;
+  bool cst;
   {
     wm::RawTile raw;
     load_raw<ALIGNED>(host + off, g.row_stride, raw);
+    // A wave of constant tiles only (letterbox bars, flat backgrounds) has nothing to iterate on: all of them are
+    // rank-deficient and go to the constant list, which k_embed_fallback finishes in closed form
+    // (wm::embed_tile_constant).  A constant tile in a mixed wave rides the iteration along and goes to the same list.
+    cst = wm::raw_is_constant(raw);
+    if (__builtin_amdgcn_ballot_w64(!cst) == 0ull) {
+      append_deficient(true, 1);
+      return;
+    }
 #if !defined(WM_NO_ASM_JACOBI)
     // sweeps 1-3 run untested, the 4th is the first that can be the last, pairs are skipped from the 5th on
     sweeps = jacobi_cols_gfx950(raw.lo, raw.hi, a, n2, wm::JAC_CONV2, wm::JAC_SKIP2, 4, 4) ? -1 : 1;
@@ -315,23 +340,13 @@ __device__ __forceinline__ void embed_group(
 #pragma unroll
     for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
     wm::embed_coeffs_pk(n2, sw, alpha_k, e, sc, deficient);
+    deficient = deficient || cst;              // (a constant tile always is: sigma_8 = 0)
     // flagged tiles are left untouched: stego may alias host (in-place embedding) and the
     // fallback kernel must still read the original pixels; it also writes their Sc
     if (!deficient) store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
   }
-  // deficient tiles are appended (wave-aggregated) to the fallback list
-  const unsigned long long dmask = __builtin_amdgcn_ballot_w64(deficient);
-  if (dmask != 0ull) {
-    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const unsigned leader = (unsigned)__builtin_ctzll(dmask);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(status + 1, (int)__builtin_popcountll(dmask));
-    base = __builtin_amdgcn_readlane(base, leader);
-    if (deficient) {
-      const unsigned rank = (unsigned)__builtin_popcountll(dmask & ((1ull << lane) - 1ull));
-      fb_list[base + rank] = (uint32_t)(plane * g.n_tiles + t);
-    }
-  }
+  append_deficient(deficient && !cst, 0);
+  append_deficient(cst, 1);
   if (sweeps < 0) atomicOr(status, 1);
   float* ywp = YW ? yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8 : nullptr;
 #pragma nounroll
@@ -354,38 +369,31 @@ __global__ __launch_bounds__(WAVE, WM_EMBED_WAVES) void k_embed_tiles(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const unsigned n_groups, const size_t sw_plane_stride,
-    const float alpha, const int K, int* __restrict__ status, uint32_t* __restrict__ fb_list) {
+    const float alpha, const int K, int* __restrict__ status, uint32_t* __restrict__ fb_list, const uint32_t fb_last) {
   const unsigned w = blockIdx.x;
   const unsigned plane = w / n_groups, grp = w - plane * n_groups;
   const int t = (int)(grp * WAVE + threadIdx.x);
   if (t >= g.n_tiles) return;
   const int ty = t / g.nbx, tx = t - ty * g.nbx;
-  embed_group<ALIGNED, YW>(host, sigma_w, stego, sigma_c, yw, g, sw_plane_stride, alpha, K, status, fb_list,
+  embed_group<ALIGNED, YW>(host, sigma_w, stego, sigma_c, yw, g, sw_plane_stride, alpha, K, status, fb_list, fb_last,
                            t, ty, tx, (size_t)plane);
 }
 
-// Literal chain with orthonormal completion (wm::embed_tile_completed) for the
-// tiles listed by the fast kernel; one listed tile per lane, a fixed grid
-// strides the list (count is only known on the device).
+// The tiles listed by the fast kernel, one per lane, a fixed grid striding each list (the counts are only known on
+// the device): first the literal chain with orthonormal completion (wm::embed_tile_completed) for the front list,
+// then the closed form of the constant tiles (wm::embed_tile_constant) for the back list.
 template <bool ALIGNED, bool YW>
 __global__ __launch_bounds__(WAVE, 2) void k_embed_fallback(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status, const uint32_t* __restrict__ fb_list) {
-  const int count = status[1];
-  for (int it = blockIdx.x * WAVE + threadIdx.x; it < count; it += gridDim.x * WAVE) {
-    const uint32_t id = fb_list[it];
-    const size_t plane = id / (uint32_t)g.n_tiles;
-    const int t = (int)(id % (uint32_t)g.n_tiles);
-    const int ty = t / g.nbx, tx = t - ty * g.nbx;
-    const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
-    float a[8][8], sw[8], sc[8], alpha_k[8];
-    load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
-    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const uint32_t fb_last) {
+  const int count = status[1], n_const = status[2];
+  float alpha_k[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
-    if (wm::embed_tile_completed(a, sw, alpha_k, sc) < 0) atomicOr(status, 1);
+  for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
+  auto finish = [&](const size_t plane, const int t, const size_t off, const float (&sc)[8], float (&a)[8][8]) {
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
     store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
     store_tile_u8<ALIGNED>(stego + off, g.row_stride, a);
     if (YW) {
@@ -393,6 +401,35 @@ __global__ __launch_bounds__(WAVE, 2) void k_embed_fallback(
 #pragma unroll
       for (int r = 0; r < 8; ++r) store_row8_f32<false>(o + (size_t)r * g.W, a[r]);
     }
+  };
+  for (int it = blockIdx.x * WAVE + threadIdx.x; it < count; it += gridDim.x * WAVE) {
+    const uint32_t id = fb_list[it];
+    const size_t plane = id / (uint32_t)g.n_tiles;
+    const int t = (int)(id % (uint32_t)g.n_tiles);
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
+    const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
+    float a[8][8], sw[8], sc[8];
+    load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
+    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+    if (wm::embed_tile_completed(a, sw, alpha_k, sc) < 0) atomicOr(status, 1);
+    finish(plane, t, off, sc, a);
+  }
+  for (int it = blockIdx.x * WAVE + threadIdx.x; it < n_const; it += gridDim.x * WAVE) {
+    const uint32_t id = fb_list[fb_last - (uint32_t)it];
+    const size_t plane = id / (uint32_t)g.n_tiles;
+    const int t = (int)(id % (uint32_t)g.n_tiles);
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
+    const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
+    float a[8][8], sw[8], sc[8];
+    const float v0 = (float)host[off];                    // every pixel of the tile has this value
+    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+    // the table is a compile-time constant when the wave's tiles are all black or none of them is (bit-identical
+    // to the general form, which adds 0 * the other table)
+    const unsigned long long bm = __builtin_amdgcn_ballot_w64(v0 == 0.0f);
+    if (bm == 0ull) wm::embed_tile_constant_t<1>(v0, sw, alpha_k, sc, a);
+    else if (bm == __builtin_amdgcn_ballot_w64(true)) wm::embed_tile_constant_t<0>(v0, sw, alpha_k, sc, a);
+    else wm::embed_tile_constant(v0, sw, alpha_k, sc, a);
+    finish(plane, t, off, sc, a);
   }
 }
 
@@ -723,8 +760,8 @@ int wm_create(int device, void* stream, wm_ctx** ctx_out) {
     if (e != hipSuccess) { delete ctx; return set_err(WM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ctx->owns_stream = true;
   }
-  hipError_t e = hipMalloc((void**)&ctx->d_status, 2 * sizeof(int));   // [0] status, [1] fallback count
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 2 * sizeof(int), ctx->stream);
+  hipError_t e = hipMalloc((void**)&ctx->d_status, 3 * sizeof(int));   // [0] status, [1] literal-fallback count, [2] constant-tile count
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 3 * sizeof(int), ctx->stream);
   for (int i = 0; i < N_EVENTS && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
   if (e != hipSuccess) { wm_destroy(ctx); return set_err(WM_ERR_HIP, "context setup: %s", hipGetErrorString(e)); }
   *ctx_out = ctx;
@@ -847,16 +884,18 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
     if (n_all > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 tiles in one call");   // ids are uint32, the device-side count an int
     const size_t n_waves = (n_all + WAVE - 1) / WAVE;
     WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, n_all * sizeof(uint32_t), "fallback list"));
-    WM_HIP(hipMemsetAsync(ctx->d_status + 1, 0, sizeof(int), ctx->stream));
+    WM_HIP(hipMemsetAsync(ctx->d_status + 1, 0, 2 * sizeof(int), ctx->stream));
     uint32_t* fb = (uint32_t*)ctx->fb_list;
+    const uint32_t fb_last = (uint32_t)(n_all - 1);      // the constant tiles' list grows down from here
     const dim3 fgrid((unsigned)(n_waves < 2048 ? n_waves : 2048));
 #define WM_LAUNCH_EMBED(A, Y)                                                                      \
   do {                                                                                             \
     hipLaunchKernelGGL((k_embed_tiles<A, Y>), grid, block, 0, ctx->stream, host, sigma_w, stego,   \
                        sigma_c, yw, g, n_groups, sigma_w_plane_stride, alpha, K,                   \
-                       ctx->d_status, fb);                                                          \
+                       ctx->d_status, fb, fb_last);                                                 \
     hipLaunchKernelGGL((k_embed_fallback<A, Y>), fgrid, block, 0, ctx->stream, host, sigma_w,      \
-                       stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb);  \
+                       stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb,   \
+                       fb_last);                                                                   \
   } while (0)
     if (al && yw) WM_LAUNCH_EMBED(true, true);
     else if (al) WM_LAUNCH_EMBED(true, false);

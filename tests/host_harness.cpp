@@ -142,7 +142,8 @@ int hh_embed_tiles_u8_pk(const uint8_t* host, const float* sigma_w, uint8_t* ste
       if (deficient) {
         ++nf;
         raw_to_f32(raw, y);
-        s = embed_tile_completed(y, sw, alpha_k, sc);
+        if (raw_is_constant(raw)) { embed_tile_constant(y[0][0], sw, alpha_k, sc, y); s = 1; }   // like k_embed_fallback
+        else s = embed_tile_completed(y, sw, alpha_k, sc);
         for (int r = 0; r < 8; ++r) {
           out.lo[r] = quant_u8(y[r][0]) | (quant_u8(y[r][1]) << 8) | (quant_u8(y[r][2]) << 16) | (quant_u8(y[r][3]) << 24);
           out.hi[r] = quant_u8(y[r][4]) | (quant_u8(y[r][5]) << 8) | (quant_u8(y[r][6]) << 16) | (quant_u8(y[r][7]) << 24);
@@ -174,6 +175,18 @@ int hh_sigma_tiles_u8_pk(const uint8_t* plane, float* sigma, int H, int W, int r
       for (int i = 0; i < 8; ++i) sigma[((size_t)ty * nbx + tx) * 8 + i] = s[i];
     }
   return 0;
+}
+
+// one constant tile of value v through the closed form and through the literal chain (both Yw [8][8] and Sc [8])
+void hh_constant_tile_both_ways(float v, const float* sw, const float* alpha_k, float* yw_closed, float* sc_closed,
+                                float* yw_literal, float* sc_literal) {
+  float swa[8], ak[8], sc[8], a[8][8];
+  for (int i = 0; i < 8; ++i) { swa[i] = sw[i]; ak[i] = alpha_k[i]; }
+  embed_tile_constant(v, swa, ak, sc, a);
+  memcpy(yw_closed, a, sizeof(a)); memcpy(sc_closed, sc, sizeof(sc));
+  for (int r = 0; r < 8; ++r) for (int c = 0; c < 8; ++c) a[r][c] = v;
+  embed_tile_completed(a, swa, ak, sc);
+  memcpy(yw_literal, a, sizeof(a)); memcpy(sc_literal, sc, sizeof(sc));
 }
 
 void hh_dct8x8(float* tile, int inverse) {

@@ -133,6 +133,55 @@ def test_rank_deficient_tiles_on_gpu(gpu_ctx):
     assert np.abs(np.matmul(Vt, Vt.swapaxes(-1, -2)) - I).max() < 1e-5
 
 
+def test_constant_tiles_take_the_closed_form(gpu_ctx):
+    """Letterbox bars / flat areas: constant tiles are finished in closed form (wm::embed_tile_constant) whether a
+    whole wave is constant (the fast kernel skips its iteration) or they sit next to textured or rank-deficient
+    tiles.  The device result equals the CPU build of the same arithmetic bit for bit on those tiles (pure FMA chains
+    over tabulated constants), the reference's invariant svd(Yw) = Sc + alpha Sw holds, the rest of the plane is
+    unchanged by their presence, and in-place embedding gives the same plane."""
+    import ctypes as C
+    import __graft_entry__ as ge
+    hh = C.CDLL(ge.build_host_harness())
+    vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(77)
+    H, W = 128, 1024                                             # 128 tiles per row: two waves per tile row
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[:24] = 16; img[-24:] = 0                                 # bars: whole waves of constant tiles (studio and full-range black)
+    img[40:56, 100:300] = 255                                    # a flat patch inside texture: mixed waves
+    img[64:72, 512:] = np.arange(8, dtype=np.uint8)[:, None] * 30    # rank-1, not constant, next to ...
+    img[64:72, 600:700] = 90                                     # ... constant tiles in the same wave
+    nby, nbx = H // 8, W // 8
+    sw = np.sort(rng.uniform(1, 1500, (nby, nbx, 8)).astype(np.float32), axis=-1)[..., ::-1].copy()
+    stego, sc, yw = gpu_ctx.embed_tiles(img, sw, 0.15, want_yw=True)
+    st_h = np.empty_like(img); sc_h = np.empty((nby * nbx, 8), np.float32); yw_h = np.empty((H, W), np.float32)
+    ms = C.c_int(0); nf = C.c_int(0)
+    hh.hh_embed_tiles_u8_pk(vp(img), vp(sw), vp(st_h), vp(sc_h), vp(yw_h), H, W, W, C.c_float(0.15), 8, C.byref(ms), C.byref(nf))
+    tiles = img.reshape(nby, 8, nbx, 8).transpose(0, 2, 1, 3)
+    const = (tiles == tiles[:, :, :1, :1]).all(axis=(2, 3))
+    assert const.sum() == 6 * nbx + 2 * 24 + 12               # bars + the tiles fully inside the two flat patches
+    T = lambda x: x.reshape(nby, 8, nbx, 8).transpose(0, 2, 1, 3)
+    assert np.array_equal(T(yw)[const], T(yw_h)[const])          # closed form: the same FMA chain on both sides
+    assert np.array_equal(sc[const], sc_h.reshape(nby, nbx, 8)[const])
+    # full-rank tiles: GPU vs CPU build as everywhere (rank-deficient non-constant ones - the rank-1 strip, tiles cut by a
+    # patch edge - go through the literal completion, whose directions are only defined as a set)
+    full = np.linalg.matrix_rank(tiles.astype(np.float64)) == 8
+    d = np.abs(T(stego).astype(int) - T(st_h).astype(int))[full]
+    assert full.sum() > 1000 and d.max() <= 1 and np.mean(d != 0) < 1e-3
+    got = np.linalg.svd(T(yw)[const].astype(np.float64), compute_uv=False)
+    want = np.sort(sc[const].astype(np.float64) + 0.15 * sw[const], axis=-1)[:, ::-1]
+    assert np.max(np.abs(got - want) / np.maximum(want[:, :1], 1.0)) < 1e-4
+    assert np.array_equal(stego, np.clip(yw, 0, 255).astype(np.uint8))
+    # the textured tiles do not care what the bars hold
+    img2 = img.copy(); img2[:24] = rng.integers(0, 256, (24, W), dtype=np.uint8)
+    stego2, _, _ = gpu_ctx.embed_tiles(img2, sw, 0.15)
+    assert np.array_equal(stego2[24:], stego[24:])
+    # in place (stego aliases host): the constant tiles are still read after the fast kernel has written its tiles
+    buf = img.copy(); sc_ip = np.empty((nby * nbx, 8), np.float32)
+    cp = lambda a_: C.c_void_p(a_.ctypes.data)
+    gpu_ctx._call("wm_embed_tiles_u8", cp(buf), cp(sw), cp(buf), cp(sc_ip), None, 1, H, W, W, H * W, 0, 0.15, 8)
+    assert np.array_equal(buf, stego) and np.array_equal(sc_ip.reshape(sc.shape), sc)
+
+
 def test_unaligned_and_strided_planes(gpu_ctx, hostapi):
     """Byte-wise kernel variants: row stride / base address not multiples of 8,
     planes embedded in a larger buffer (row_stride > W, plane_stride > H*row_stride)."""

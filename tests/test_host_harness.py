@@ -13,6 +13,7 @@ import __graft_entry__ as ge
 from oracle import wm_oracle as o
 
 SIGMA_RTOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -192,6 +193,31 @@ def test_rank_deficient_tiles_get_an_orthonormal_completion(hh):
     assert np.abs(np.matmul(Vt, Vt.transpose(0, 2, 1)) - I).max() < 1e-5
     C0 = o._dct_tiles(o.to_tiles(wflat)).reshape(4, 8, 8)
     assert np.abs(np.matmul(U * S[:, None, :], Vt) - C0).max() < 1e-3
+
+
+def test_constant_tile_closed_form_equals_the_literal_chain(hh):
+    """embed_tile_constant (tabulated completion of a constant tile) against embed_tile_completed on the same tile:
+    Yw within 2e-2 grey levels, Sc within 1e-6 * max(8 v, 1) - for black, dark, mid, white tiles, K = 8 and K = 3 -
+    and the committed tables are the generator's output."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_completion_tables as gt
+    inc = os.path.join(ROOT, "digital-watermarking-for-image-video-using-dct-svd-singular-value-decomposition_amd", "csrc",
+                       "wm_completion_tables.inc")
+    assert open(inc).read() == gt.render()
+    rng = np.random.default_rng(3)
+    for v in (0.0, 1.0, 16.0, 128.0, 235.0, 255.0):
+        for K in (8, 3):
+            sw = np.sort(rng.uniform(1.0, 2000.0, 8))[::-1].astype(np.float32).copy()
+            ak = np.array([0.15 if i < K else 0.0 for i in range(8)], np.float32)
+            yc = np.empty((8, 8), np.float32); yl = np.empty((8, 8), np.float32)
+            scc = np.empty(8, np.float32); scl = np.empty(8, np.float32)
+            hh.hh_constant_tile_both_ways(C.c_float(v), vp(sw), vp(ak), vp(yc), vp(scc), vp(yl), vp(scl))
+            assert np.max(np.abs(yc - yl)) < 2e-2, (v, K, np.max(np.abs(yc - yl)))
+            assert np.max(np.abs(scc - scl)) < 1e-6 * max(8 * v, 1.0), (v, K, scc, scl)
+            # and the reference's invariant: svd(Yw) = Sc + alpha Sw on the first K (the completion is orthonormal)
+            got = np.linalg.svd(yc.astype(np.float64), compute_uv=False)
+            want = np.sort(scc.astype(np.float64) + ak * sw)[::-1]
+            assert np.max(np.abs(got - want)) < 1e-3 * max(want[0], 1.0)
 
 
 def test_tile_math_under_sanitizers(tmp_path):

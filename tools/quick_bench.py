@@ -20,9 +20,10 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--alpha", type=float, default=0.15)
-    ap.add_argument("--content", default="noise", choices=["noise", "natural", "screen", "flat"],
+    ap.add_argument("--content", default="noise", choices=["noise", "natural", "screen", "flat", "letterbox"],
                     help="noise: iid uint8; natural: smooth field + sensor noise; screen: flat rectangles "
-                         "+ 1-px strokes (mostly rank-deficient tiles); flat: one constant")
+                         "+ 1-px strokes (mostly rank-deficient tiles); flat: one constant; letterbox: natural content "
+                         "between black bars (2.39:1 in 16:9: a quarter of the tiles constant)")
     a = ap.parse_args()
     H, W, F = a.H, a.W, a.frames
     nt = (H // 8) * (W // 8)
@@ -30,7 +31,7 @@ def main():
     rng = np.random.default_rng(1234)
     if a.content == "noise":
         host = rng.integers(0, 256, (F, H, W), dtype=np.uint8)
-    elif a.content == "natural":
+    elif a.content in ("natural", "letterbox"):
         low = rng.uniform(20, 235, (F, H // 16 + 2, W // 16 + 2)).astype(np.float32)
         up = np.kron(low, np.ones((16, 16), np.float32))[:, 8:8 + H, 8:8 + W]
         for ax in (1, 2):                       # box blur 16 -> piecewise-linear field
@@ -38,6 +39,9 @@ def main():
             up = (np.take(c, np.arange(16, c.shape[ax]), axis=ax) - np.take(c, np.arange(0, c.shape[ax] - 16), axis=ax)) / 16
             pad = [(0, 0)] * 3; pad[ax] = (8, 8); up = np.pad(up, pad, mode="edge")
         host = np.clip(up + rng.normal(0, 2.0, up.shape), 0, 255).astype(np.uint8)
+        if a.content == "letterbox":
+            bar = int(round((H - W / 2.39) / 2 / 8)) * 8
+            host[:, :bar] = 16; host[:, H - bar:] = 16
     elif a.content == "screen":
         host = np.full((F, H, W), 240, np.uint8)
         for f in range(F):
