@@ -263,6 +263,61 @@ WM_HD v2f fma2(v2f a, v2f b, v2f c) {
 #endif
 }
 
+// dct8 / idct8 on packed row pairs (both rows of a pair at once): the row pass of the 2-D transform in the layout
+// the iteration works in.  Same formulas as the scalar forms above.
+WM_HD void dct8_pk(v2f& x0, v2f& x1, v2f& x2, v2f& x3, v2f& x4, v2f& x5, v2f& x6, v2f& x7) {
+  const v2f s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
+  const v2f d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
+  const v2f e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+  x0 = splat2(C4) * (e0 + e1);
+  x4 = splat2(C4) * (e0 - e1);
+  x2 = fma2(splat2(C2), e2, splat2(C6) * e3);
+  x6 = fma2(splat2(C6), e2, splat2(-C2) * e3);
+  x1 = fma2(splat2(C1), d0, fma2(splat2(C3), d1, fma2(splat2(C5), d2, splat2(C7) * d3)));
+  x3 = fma2(splat2(C3), d0, fma2(splat2(-C7), d1, fma2(splat2(-C1), d2, splat2(-C5) * d3)));
+  x5 = fma2(splat2(C5), d0, fma2(splat2(-C1), d1, fma2(splat2(C7), d2, splat2(C3) * d3)));
+  x7 = fma2(splat2(C7), d0, fma2(splat2(-C5), d1, fma2(splat2(C3), d2, splat2(-C1) * d3)));
+}
+WM_HD void idct8_pk(v2f& x0, v2f& x1, v2f& x2, v2f& x3, v2f& x4, v2f& x5, v2f& x6, v2f& x7) {
+  const v2f p = splat2(C4) * (x0 + x4), q = splat2(C4) * (x0 - x4);
+  const v2f r = fma2(splat2(C2), x2, splat2(C6) * x6), t = fma2(splat2(C6), x2, splat2(-C2) * x6);
+  const v2f e0 = p + r, e3 = p - r, e1 = q + t, e2 = q - t;
+  const v2f o0 = fma2(splat2(C1), x1, fma2(splat2(C3), x3, fma2(splat2(C5), x5, splat2(C7) * x7)));
+  const v2f o1 = fma2(splat2(C3), x1, fma2(splat2(-C7), x3, fma2(splat2(-C1), x5, splat2(-C5) * x7)));
+  const v2f o2 = fma2(splat2(C5), x1, fma2(splat2(-C1), x3, fma2(splat2(C7), x5, splat2(C3) * x7)));
+  const v2f o3 = fma2(splat2(C7), x1, fma2(splat2(-C5), x3, fma2(splat2(C3), x5, splat2(-C1) * x7)));
+  x0 = e0 + o0; x7 = e0 - o0;
+  x1 = e1 + o1; x6 = e1 - o1;
+  x2 = e2 + o2; x5 = e2 - o2;
+  x3 = e3 + o3; x4 = e3 - o3;
+}
+// dct2 of a[row][col] into the packed form b[rp][c] = (C[2 rp][c], C[2 rp + 1][c]): column pass on the scalars, row pass
+// on the pairs; and back.  (Packing the result of dct8x8 instead makes the compiler re-pair through scratch memory.)
+WM_HD void dct8x8_to_pk(const float (&a)[8][8], v2f (&b)[4][8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {               // column pass, results straight into the pairs
+    float x0 = a[0][c], x1 = a[1][c], x2 = a[2][c], x3 = a[3][c], x4 = a[4][c], x5 = a[5][c], x6 = a[6][c], x7 = a[7][c];
+    dct8(x0, x1, x2, x3, x4, x5, x6, x7);
+    const v2f p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7};
+    b[0][c] = p0; b[1][c] = p1; b[2][c] = p2; b[3][c] = p3;
+  }
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp)
+    dct8_pk(b[rp][0], b[rp][1], b[rp][2], b[rp][3], b[rp][4], b[rp][5], b[rp][6], b[rp][7]);
+}
+WM_HD void idct8x8_from_pk(v2f (&b)[4][8], float (&a)[8][8]) {
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp)
+    idct8_pk(b[rp][0], b[rp][1], b[rp][2], b[rp][3], b[rp][4], b[rp][5], b[rp][6], b[rp][7]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float x0 = b[0][c][0], x1 = b[0][c][1], x2 = b[1][c][0], x3 = b[1][c][1];
+    float x4 = b[2][c][0], x5 = b[2][c][1], x6 = b[3][c][0], x7 = b[3][c][1];
+    idct8(x0, x1, x2, x3, x4, x5, x6, x7);
+    a[0][c] = x0; a[1][c] = x1; a[2][c] = x2; a[3][c] = x3; a[4][c] = x4; a[5][c] = x5; a[6][c] = x6; a[7][c] = x7;
+  }
+}
+
 // acc + (ab[HALF], ab[HALF]) * x  and  (ab[HALF], ab[HALF]) * x : the broadcast is the packed
 // instruction's op_sel, written out so that the compiler cannot materialise (and then hoist and
 // spill) the 64 broadcast pairs of B the embed epilogue reads.
@@ -653,6 +708,19 @@ WM_HD void add_completion(float (&a)[8][8], const float scale) {
     for (int c = 0; c < 8; ++c) a[r][c] = ffma(scale, COMPLETION_PATTERN[r][c], a[r][c]);
 }
 
+// the same on the packed form (rows 2 rp, 2 rp + 1 of column c in one v2f): what the literal chain uses, so that the
+// pattern is added in the layout the iteration works in (added to a[r][c] the compiler pairs neighbouring COLUMNS
+// and re-pairs them through scratch memory)
+WM_HD void add_completion_pk(v2f (&b)[4][8], const float scale) {
+#pragma unroll
+  for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const v2f pt = {COMPLETION_PATTERN[2 * rp][c], COMPLETION_PATTERN[2 * rp + 1][c]};
+      b[rp][c] = fma2(splat2(scale), pt, b[rp][c]);
+    }
+}
+
 // ---- packed one-sided Jacobi WITH V: A and V stacked as one 16-row matrix ----
 // The same rotation (jacobi_rot_pk's two-rsq angle) is applied to the 4 row pairs
 // of A and the 4 row pairs of V; dot products and norms come from the A half only.
@@ -740,17 +808,10 @@ WM_HD int jacobi_cols_pk_v(v2f (&a)[4][8], v2f (&v)[4][8], float (&n2)[8], float
 // with V -> U diag(S + alpha Sw) V^T -> (-delta P) -> idct2
 WM_HD int embed_tile_completed(float (&a)[8][8], const float (&sw)[8], const float (&alpha_k)[8],
                                float (&sc)[8]) {
-  dct8x8(a);
-  add_completion(a, COMPLETION_DELTA);
   v2f b[4][8], v[4][8];
   float n2[8], vn2[8];
-#pragma unroll
-  for (int rp = 0; rp < 4; ++rp)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      v2f t = {a[2 * rp][c], a[2 * rp + 1][c]};
-      b[rp][c] = t;
-    }
+  dct8x8_to_pk(a, b);
+  add_completion_pk(b, COMPLETION_DELTA);
   const int sweeps = jacobi_cols_pk_v(b, v, n2, vn2);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -764,6 +825,7 @@ WM_HD int embed_tile_completed(float (&a)[8][8], const float (&sw)[8], const flo
     for (int rp = 0; rp < 4; ++rp) b[rp][i] = b[rp][i] * splat2(f);
   }
   // Cw = sum_i (b_i f_i) v_i^T   ==  U diag(S_) V^T ; row pair rp, column c
+  v2f cw[4][8];
 #pragma unroll
   for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -771,11 +833,10 @@ WM_HD int embed_tile_completed(float (&a)[8][8], const float (&sw)[8], const flo
       v2f acc = b[rp][0] * splat2(v[c >> 1][0][c & 1]);
 #pragma unroll
       for (int i = 1; i < 8; ++i) acc = fma2(b[rp][i], splat2(v[c >> 1][i][c & 1]), acc);
-      a[2 * rp][c] = acc[0];
-      a[2 * rp + 1][c] = acc[1];
+      const v2f pt = {COMPLETION_PATTERN[2 * rp][c], COMPLETION_PATTERN[2 * rp + 1][c]};
+      cw[rp][c] = fma2(splat2(-COMPLETION_DELTA), pt, acc);
     }
-  add_completion(a, -COMPLETION_DELTA);
-  idct8x8(a);
+  idct8x8_from_pk(cw, a);
   return sweeps;
 }
 
@@ -792,17 +853,10 @@ WM_HD int sigma_tile(float (&a)[8][8], float (&s)[8]) {
 // ---- full SVD of a float tile (watermark side): U, S, Vt --------------------
 // u[r][i], vt[i][c]; columns with sigma == 0 get u_i = 0.
 WM_HD int svd_tile(float (&a)[8][8], float (&s)[8], float (&vt)[8][8], const bool complete = false) {
-  dct8x8(a);
-  if (complete) add_completion(a, COMPLETION_DELTA);
   v2f b[4][8], v[4][8];
   float n2[8], vn2[8];
-#pragma unroll
-  for (int rp = 0; rp < 4; ++rp)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      v2f t = {a[2 * rp][c], a[2 * rp + 1][c]};
-      b[rp][c] = t;
-    }
+  dct8x8_to_pk(a, b);
+  if (complete) add_completion_pk(b, COMPLETION_DELTA);
   const int sweeps = jacobi_cols_pk_v(b, v, n2, vn2);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

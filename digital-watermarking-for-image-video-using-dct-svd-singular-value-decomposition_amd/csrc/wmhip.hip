@@ -382,8 +382,11 @@ __global__ __launch_bounds__(WAVE, WM_EMBED_WAVES) void k_embed_tiles(
 // The tiles listed by the fast kernel, one per lane, a fixed grid striding each list (the counts are only known on
 // the device): first the literal chain with orthonormal completion (wm::embed_tile_completed) for the front list,
 // then the closed form of the constant tiles (wm::embed_tile_constant) for the back list.
+#ifndef WM_FALLBACK_WAVES
+#define WM_FALLBACK_WAVES 2
+#endif
 template <bool ALIGNED, bool YW>
-__global__ __launch_bounds__(WAVE, 2) void k_embed_fallback(
+__global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const size_t sw_plane_stride, const float alpha, const int K,

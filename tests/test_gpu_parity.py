@@ -445,11 +445,12 @@ def test_generated_jacobi_stream_against_the_cpp_form_on_the_gpu(hostapi):
     wys = rng.integers(0, 256, (H, W)).astype(np.float32)
     wys[:64] = 77.0                                 # rank-1 tiles and ...
     wys[64:128] = ((yy + xx) % 2 * 255)[64:128]     # ... rank-2 tiles on the watermark side too (the stream with V)
-    res, svds = [], []
+    res, svds, yws = [], [], []
     for ctx in (hostapi.Context(0), Ctx(lib)):
         U, S, Vt = ctx.svd_tiles(wys)
         svds.append((U, S, Vt))
-        st, sc, _ = ctx.embed_tiles(planes, S, 0.15)
+        st, sc, yw_ = ctx.embed_tiles(planes, S, 0.15, want_yw=True)
+        yws.append(yw_)
         sig = ctx.sigma_tiles(st)
         w = ctx.extract_tiles(st, sc, U, Vt, 0.15)
         d = ctx.detect_tiles(st, sc, S, 0.15)
@@ -463,13 +464,22 @@ def test_generated_jacobi_stream_against_the_cpp_form_on_the_gpu(hostapi):
     assert np.max(np.abs(np.einsum("...ic,...jc->...ij", Vt_a, Vt_a) - np.eye(8))) < 1e-5
     assert np.max(np.abs(sc_a - sc_c) / np.maximum(sc_c[..., :1], 1.0)) < 2e-6
     dd = np.abs(st_a.astype(int) - st_c.astype(int))
-    assert dd.max() <= 1 and np.mean(dd != 0) < 1e-4
+    assert dd[:3].max() <= 1 and np.mean(dd[:3] != 0) < 1e-4
+    # the checkerboard's tiles have a REPEATED singular value (255 * 4 twice): the basis inside that plane is arbitrary,
+    # the two builds may pick different ones and the injected alpha * (sw_1 u_1 v_1^T + sw_2 u_2 v_2^T) differs with it.
+    # What is defined there is the reference's invariant, for each build on its own:
+    nby, nbx = H // 8, W // 8
+    for yw_, sc_, S_ in zip(yws, (sc_a, sc_c), (S_a, S_c)):
+        Tt = yw_[3].reshape(nby, 8, nbx, 8).transpose(0, 2, 1, 3).reshape(-1, 8, 8).astype(np.float64)
+        got = np.linalg.svd(Tt, compute_uv=False)
+        want = np.sort(sc_[3].reshape(-1, 8).astype(np.float64) + 0.15 * S_.reshape(-1, 8), axis=1)[:, ::-1]
+        assert np.max(np.abs(got - want) / np.maximum(want[:, :1], 1.0)) < 1e-4
     # sigma-only kernels on IDENTICAL input (the asm library's stego through both)
     ctx = Ctx(lib)
     sig_c2 = ctx.sigma_tiles(st_a)
     ctx.close()
     assert np.max(np.abs(sig_a - sig_c2) / np.maximum(sig_c2[..., :1], 1.0)) < 2e-5    # skip threshold 1e-8: bounded at 5e-5 s_i
-    assert np.abs(d_a - d_c).max() < 2e-3
+    assert np.abs(d_a - d_c)[:3].max() < 2e-3          # (plane 3: two different valid stegos, see above)
 
 
 def test_device_dct_against_the_published_jpeg_example(gpu_ctx):
