@@ -264,8 +264,10 @@ def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0)
 def embed(cover_path: str, wm_source: str, out_path: str, meta_path: str,
           alpha: float = 0.1, color: bool = False, password: Optional[str] = None,
           kfrac: float = K_FRAC_DEFAULT, *, tile: Optional[int] = TILE, k_floor: int = 8,
-          nonce: Optional[bytes] = None, device: int = 0):
-    """single:112-190.  Returns (out_path, meta_path, psnr, ssim)."""
+          nonce: Optional[bytes] = None, device: int = 0, compress_meta: bool = True):
+    """single:112-190.  Returns (out_path, meta_path, psnr, ssim).  ``compress_meta=False`` writes the .npz
+    uncompressed (np.load - and the reference's extract / detect - read either form): the tile-mode factors are
+    float noise to zlib, and compressing the 70 MB of a 4K cover costs ten times the rest of the call."""
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để nhúng.")
     cover = hg.read_image_bgr(cover_path)                                  # single:117
@@ -277,7 +279,7 @@ def embed(cover_path: str, wm_source: str, out_path: str, meta_path: str,
         out_path = os.path.splitext(out_path)[0] + "_stego.png"            # single:148-149,178-179
     if not hg.write_png(out_path, r["stego"], 0):                          # single:150,180
         raise IOError("Ghi stego thất bại.")
-    np.savez_compressed(meta_path, **r["meta"])                            # single:157-166,183-189
+    (np.savez_compressed if compress_meta else np.savez)(meta_path, **r["meta"])   # single:157-166,183-189
     return out_path, meta_path, r["psnr"], r["ssim"]
 
 

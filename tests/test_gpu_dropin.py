@@ -81,6 +81,12 @@ def test_file_level_roundtrip(core, tmp_path, color):
         core.extract(out, meta + ".npz", str(tmp_path / "x.png"), password="nope")
     with pytest.raises(ValueError):
         core.embed(cp, wp, out, meta, password="")
+    # uncompressed meta: the same arrays, readable the same way
+    _, meta_u, _, _ = core.embed(cp, wp, str(tmp_path / "result_u.png"), str(tmp_path / "mu"), alpha=0.12, color=color,
+                                 password="pw", nonce=bytes(8), compress_meta=False)
+    du = np.load(meta_u + ".npz", allow_pickle=False)
+    assert set(du.files) == want and all(np.array_equal(du[k], data[k]) for k in want)
+    assert core.detect(str(tmp_path / "result_u.png"), meta_u + ".npz")[0]
     with pytest.raises(ValueError):
         core.embed(str(tmp_path / "missing.png"), wp, out, meta, password="pw")
     with pytest.raises(ValueError):
