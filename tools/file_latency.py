@@ -11,16 +11,17 @@ yy, xx = np.mgrid[0:1080, 0:1920]
 cover = np.clip(128 + 70 * np.sin(xx / 37.0)[..., None] * np.cos(yy / 23.0)[..., None] + rng.normal(0, 6, (1080, 1920, 3)), 0, 255).astype(np.uint8)
 Image.fromarray(cover).save(os.path.join(d, "cover.png"), compress_level=1)
 Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(os.path.join(d, "wm.png"))
-for tile in (8, None):
-    for color in (False, True):
+for tile, color, cm in ((8, False, True), (8, False, False), (8, True, True), (8, True, False), (None, False, True), (None, True, True)):
+    if True:
         for rep in range(2):
             t0 = time.perf_counter()
             out, meta, ps, ss = core.embed(os.path.join(d, "cover.png"), os.path.join(d, "wm.png"), os.path.join(d, "s.png"),
-                                           os.path.join(d, "m.npz"), alpha=0.12, color=color, password="pw", tile=tile)
+                                           os.path.join(d, "m.npz"), alpha=0.12, color=color, password="pw", tile=tile,
+                                           compress_meta=cm)
             t1 = time.perf_counter()
             core.extract(out, meta, os.path.join(d, "w.png"), password="pw")
             t2 = time.perf_counter()
             ok, score = core.detect(out, meta)
             t3 = time.perf_counter()
-        print(f"1080p tile={tile} color={color}: embed {1e3*(t1-t0):7.1f} ms  extract {1e3*(t2-t1):7.1f} ms  detect {1e3*(t3-t2):7.1f} ms  "
+        print(f"1080p tile={tile} color={color} compress_meta={cm}: embed {1e3*(t1-t0):7.1f} ms  extract {1e3*(t2-t1):7.1f} ms  detect {1e3*(t3-t2):7.1f} ms  "
               f"psnr {ps:.2f} ssim {ss:.4f} score {score:.3f}", flush=True)
