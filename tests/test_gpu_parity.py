@@ -544,3 +544,38 @@ def test_bad_args_of_the_round2_entry_points(gpu_ctx, hostapi):
     finally:
         gpu_ctx.free(d)
     gpu_ctx.check_status()
+
+
+def test_random_geometries_against_the_oracle(gpu_ctx):
+    """A sweep of odd geometries through the C ABI: plane counts that do not divide the XCD mapping, tile counts that do
+    not fill a wave, strided views, shared and per-plane watermark values, K from 0 to 8 - embed, sigma, extract, detect
+    against the oracle on every plane (sizes the oracle does in milliseconds)."""
+    rng = np.random.default_rng(2024)
+    for case in range(14):
+        n = int(rng.integers(1, 6)); H = int(rng.integers(8, 150)); W = int(rng.integers(8, 210))
+        K = int(rng.integers(0, 9)); alpha = float(rng.uniform(0.05, 0.3))
+        pad_r, pad_c = int(rng.integers(0, 9)), int(rng.integers(0, 13))
+        big = rng.integers(0, 256, (n, H + pad_r, W + pad_c), dtype=np.uint8)
+        hosts = big[:, pad_r // 2:pad_r // 2 + H, pad_c // 2:pad_c // 2 + W]          # a strided view unless both pads are 0
+        wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+        Uo, So, Vto = o.watermark_decompose(wys, 8)
+        per_plane = bool(case % 3 == 0)
+        Sw = np.stack([So * (1.0 + 0.1 * p) for p in range(n)]).astype(np.float32) if per_plane else So
+        stego, sc, yw = gpu_ctx.embed_tiles(hosts, Sw, alpha, K=K, want_yw=True)
+        sig = gpu_ctx.sigma_tiles(stego)
+        ext = gpu_ctx.extract_tiles(stego, sc, Uo, Vto, alpha, K=K)
+        det = gpu_ctx.detect_tiles(stego, sc, Sw, alpha)
+        Hb, Wb = H // 8 * 8, W // 8 * 8
+        for p in range(n):
+            swp = Sw[p] if per_plane else So
+            ref = o.embed_plane(hosts[p].astype(np.float32), wys, alpha, 0.0, 8, k_floor=K, wm_svd=(Uo, swp, Vto))
+            assert _rel_sigma(sc[p], ref["Sc"]) < SIGMA_RTOL, (case, p)
+            d = np.abs(stego[p].astype(int) - ref["stego"].astype(int))
+            assert d.max() <= 1, (case, p, n, H, W, K)                 # (K = 0: nothing is injected, both reproduce the host)
+            assert np.array_equal(stego[p][Hb:], hosts[p][Hb:]) and np.array_equal(stego[p][:, Wb:], hosts[p][:, Wb:])
+            if Hb and Wb:
+                assert _rel_sigma(sig[p], o.stego_sigma(stego[p].astype(np.float32), 8)) < SIGMA_RTOL
+                wo = o.extract_plane(stego[p].astype(np.float32), sc[p], Uo, Vto, alpha, 0.0, H, W, 8, k_floor=K)
+                assert np.abs(ext[p] - wo).max() < 5e-2 * max(1.0, 0.15 / alpha), (case, p)
+                if K > 0:     # with nothing injected the NC is a correlation of rounding residues: not comparable
+                    assert abs(det[p] - o.detect_plane(stego[p].astype(np.float32), sc[p], swp, alpha, 8)) < 1e-4
