@@ -327,3 +327,29 @@ def test_fullframe_device_pointer_entry_points_equal_the_host_forms(gpu_ctx):
     assert np.array_equal(s_d, gpu_ctx.ref_detect_planes(st_h, sc_h, S, alpha)) and s_d.min() > 0.9
     for p in (d_in, d_out, d_sw, d_sc, d_yw, d_sig, d_u, d_v, d_w, d_s):
         c.free(p)
+
+
+def test_fullframe_random_geometries(gpu_ctx):
+    """Odd sizes through the full-frame entry points: heights / widths that are not multiples of the 32-row blocks or of
+    the 128-column Gram chunks, tall and wide planes, batches of 1-3, K anywhere in 1..L - embed and sigma against the
+    float64 LAPACK oracle."""
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        H = int(rng.integers(16, 190)); W = int(rng.integers(16, 260)); n = int(rng.integers(1, 4))
+        H -= H % 2; W -= W % 2                                   # the reference's cv2.dct needs even sizes
+        L = min(H, W); K = int(rng.integers(1, L + 1)); alpha = float(rng.uniform(0.05, 0.25))
+        hosts = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+        Sw = np.sort(rng.uniform(10, 9000, L).astype(np.float32))[::-1].copy()
+        st, sc, _ = gpu_ctx.ref_embed_planes(hosts, Sw, alpha, K)
+        for p in range(n):
+            C = o.dct2(hosts[p].astype(np.float32))
+            Uc, Sc, Vct = o.svd_f32(C)
+            assert np.max(np.abs(sc[p] - Sc)) / Sc[0] < 3e-6, (case, H, W, n, K)
+            S_ = Sc.copy(); S_[:K] = Sc[:K] + alpha * Sw[:K]
+            want = np.clip(o.idct2((Uc @ np.diag(S_) @ Vct).astype(np.float32)), 0, 255).astype(np.uint8)
+            d = np.abs(st[p].astype(int) - want.astype(int))
+            assert d.max() <= 1 and np.mean(d != 0) < 5e-3, (case, H, W, n, K, int(d.max()))
+        s2 = gpu_ctx.ref_sigma_planes(st)
+        for p in range(n):
+            so = o.stego_sigma(st[p].astype(np.float32), None)
+            assert np.max(np.abs(s2[p] - so)) / so[0] < 3e-6
