@@ -315,7 +315,9 @@ __device__ __forceinline__ void embed_group(
     // A wave of constant tiles only (letterbox bars, flat backgrounds) has nothing to iterate on: all of them are
     // rank-deficient and go to the constant list, which k_embed_fallback finishes in closed form
     // (wm::embed_tile_constant).  A constant tile in a mixed wave rides the iteration along and goes to the same list.
-    cst = wm::raw_is_constant(raw);
+    // (the 16-word comparison only if some tile of the wave passes a two-word test: textured content pays 3 instructions)
+    cst = false;
+    if (__builtin_amdgcn_ballot_w64(raw.lo[0] == raw.hi[0] && raw.lo[0] == raw.hi[7]) != 0ull) cst = wm::raw_is_constant(raw);
     if (__builtin_amdgcn_ballot_w64(!cst) == 0ull) {
       append_deficient(true, 1);
       return;
