@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256) void k_sgemm(const int M, const int N, const i
     }
   };
   const int m0 = (wv >> 1) * 32, n0 = (wv & 1) * 32;
+  // Two-level accumulation: every K step of 32 is summed from zero in the matrix core (which adds its products to
+  // C one by one, round-to-nearest: tools/mfma_round_probe.hip) and the step sums are added up by the VALU.  One long
+  // chain loses every term that follows a dominant one below that term's ulp - the DC coefficient of a DCT plane
+  // leads its row by 2^11 - which made sigma_1 of the watermark-side SVD 5e-6 (1080p) to 4e-5 (8K) low.
   v16f_s acc = {0};
   fetch(0);
   int buf = 0;
@@ -113,9 +117,11 @@ __global__ __launch_bounds__(256) void k_sgemm(const int M, const int N, const i
     __syncthreads();                    // double-buffered LDS: one barrier per K step
     const float* pa = &As[buf][m0 + j][h];
     const float* pb = &Bs[buf][h][n0 + j];
+    v16f_s part = {0};
 #pragma unroll
     for (int kk = 0; kk < KS / 2; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk], pb[2 * kk * 65], acc, 0, 0, 0);
+      part = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kk], pb[2 * kk * 65], part, 0, 0, 0);
+    acc += part;
   }
   const int gn = bn + n0 + j;
   if (gn < N) {
@@ -1043,6 +1049,34 @@ int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0
     for (int i = 0; i < p.Lp; ++i) { f2 += b2[(size_t)z * p.Lp + i]; bmax[z] = std::max(bmax[z], b2[(size_t)z * p.Lp + i]); }
     floor2[z] = NULL_ROW_RATIO * NULL_ROW_RATIO * f2;
   }
+  // Scale drift of the rotated rows, measured: every row goes through the same ~3e4..3e5 rotations, each of which
+  // shrinks it by the few 1e-8 that v_rsq_f32 leaves cos^2 + sin^2 below 1, so |b_i|^2 / s_i^2 is nearly the SAME
+  // factor g < 1 for all rows of a plane (1 - g = 6e-4 at 1080p, 1.6e-3 at 8K).  Where both estimates exist (the
+  // rows above the switch below) g_i = |b_i|^4 / |T[:, i]|^2 is known; its median calibrates the rows below the
+  // switch, whose |b_i| is the only estimate: s_i = |b_i| / sqrt(g).  Without it the largest error of a whole
+  // spectrum sat right below the switch (3.3e-6 s_1 at 4K, 7.8e-6 at 8K - tests/test_gpu_fullframe_large.py).
+  static const bool drift_cal = !(getenv("WM_RF_DRIFT_CAL") && atoi(getenv("WM_RF_DRIFT_CAL")) == 0);
+  std::vector<double> gcal(p.B, 1.0);
+  {
+    const double ratio0 = T_SWITCH * (double)ctx->ref_skip_thr;
+    std::vector<double> g;
+    for (int z = 0; z < p.B; ++z) {
+      g.clear();
+      for (int i = 0; i < p.Lp; ++i) {
+        const size_t k = (size_t)z * p.Lp + i;
+        if (!(q2[k] > 0.0 && b2[k] > 0.0) || b2[k] < ratio0 * ratio0 * bmax[z]) continue;
+        const double gi = b2[k] * b2[k] / q2[k];
+        if (fabs(sqrt(q2[k]) / b2[k] - 1.0) < DRIFT_TOL) g.push_back(gi);
+      }
+      if (g.size() >= 8) {
+        std::sort(g.begin(), g.end());
+        if (drift_cal) gcal[z] = g[g.size() / 2];
+        if (getenv("WM_RF_DEBUG_DRIFT"))
+          fprintf(stderr, "[wm_ref] plane %d: drift factor g over %zu rows: p05 %.3e  median %.3e  p95 %.3e  (1 - g)\n", z,
+                  g.size(), 1.0 - g[g.size() / 20], 1.0 - g[g.size() / 2], 1.0 - g[g.size() - 1 - g.size() / 20]);
+      }
+    }
+  }
   for (size_t i = 0; i < b2.size(); ++i) {
     const double t2 = q2[i];
     // |A0 b_i^T| / |b_i| agrees with |b_i| up to the rotations' scale drift unless b_i is residue
@@ -1059,7 +1093,7 @@ int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0
     } else if (rho > RESIDUE_RHO && b2[i] < floor2[i / p.Lp]) {
       b2[i] = 0.0; q2[i] = 1.0;                                         // residue below the floor: sigma = 0
     } else {
-      q2[i] = 1.0;                                                      // sigma = |b_i|
+      q2[i] = gcal[i / p.Lp];                                           // sigma = |b_i| / sqrt(g): the norm, drift calibrated
     }
   }
   return WM_OK;
@@ -1459,8 +1493,8 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
   const RefPlan p = make_plan(H, W);
   RefWs w;
   const size_t n_in = (size_t)H * row_stride;
-  // tmp1: input plane, then sorted factor for download; tmp2: DCT intermediate
-  WM_TRY(plan_workspace(ctx, p, w, std::max(n_in, (size_t)p.M * p.L) + (size_t)H * W, (size_t)H * W));
+  // tmp1: input plane, then sorted factor for download; tmp2: DCT intermediate, then T = A0 B^T [L][Lp]
+  WM_TRY(plan_workspace(ctx, p, w, std::max(n_in, (size_t)p.M * p.L) + (size_t)H * W, std::max((size_t)H * W, (size_t)p.L * p.Lp)));
   float* d_in = w.tmp1;
   float* d_c = w.tmp1 + std::max(n_in, (size_t)p.M * p.L);     // H x W
   WM_HIP(hipMemcpyAsync(d_in, plane, n_in * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1479,7 +1513,37 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
   std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
   WM_TRY(fetch_norms(ctx, p, w, true, b2, q2));
-  sort_sigma(p, b2.data(), q2.data(), order, sig);
+  // Singular values.  |b_i| / |q_i| is exact as long as B = Qt A holds, but the two parts of a row round
+  // independently through ~1e5 MFMA row updates: measured 7e-5 relative low at 8K (3e-5 at 1080p), the same for
+  // every value.  Like the sigma-only path (fetch_norms_t) the large values are therefore measured on the untouched
+  // input, s_i = |A0 b_i^T| / |b_i| (error c^2 (s_max / s_i)^2 / 2 with the residual cosine c <= ref_skip_thr), and
+  // the ratio of the two estimates there (median) calibrates |b_i| / |q_i| for the values below the switch.
+  std::vector<double> q2s = q2;                       // q2 itself still normalises the columns of the short-side factor
+  {
+    float* d_T = w.tmp2;
+    WM_TRY(sgemm(ctx, p.transpose, true, p.L, p.Lp, p.M, 1.0f, src, (int)src_stride, w.aug, p.ld, 0.0f, d_T, p.Lp));
+    hipLaunchKernelGGL(k_rf_colnorms, dim3((p.Lp + 63) / 64, 1), dim3(256), 0, ctx->stream, d_T, (size_t)0, p.L, p.Lp, w.q2);
+    WM_HIP(hipGetLastError());
+    std::vector<double> t2(p.Lp);
+    WM_HIP(hipMemcpyAsync(t2.data(), w.q2, t2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    double smax2 = 0.0;
+    for (int i = 0; i < p.Lp; ++i) if (q2[i] > 0.0) smax2 = std::max(smax2, b2[i] / q2[i]);
+    const double ratio = T_SWITCH * (double)ctx->ref_skip_thr;
+    std::vector<double> g;
+    std::vector<unsigned char> above(p.Lp, 0);
+    for (int i = 0; i < p.Lp; ++i) {
+      if (!(b2[i] > 0.0 && q2[i] > 0.0 && t2[i] > 0.0)) continue;
+      const double s2 = b2[i] / q2[i];
+      const double rho = sqrt(t2[i] * q2[i]) / b2[i];            // |T[:, i]| against |b_i| * (|b_i| / |q_i|)
+      if (fabs(rho - 1.0) < DRIFT_TOL && s2 >= ratio * ratio * smax2) { above[i] = 1; g.push_back(b2[i] * b2[i] / (q2[i] * t2[i])); }
+    }
+    double gcal = 1.0;
+    if (g.size() >= 8) { std::sort(g.begin(), g.end()); gcal = g[g.size() / 2]; }
+    for (int i = 0; i < p.Lp; ++i)
+      q2s[i] = above[i] ? b2[i] * b2[i] / t2[i] : q2[i] * gcal;
+  }
+  sort_sigma(p, b2.data(), q2s.data(), order, sig);
   memcpy(S, sig.data(), (size_t)p.L * 4);
   // short-side factor: columns q_i/|q_i|   (rows of Qt), long-side factor: rows b_i/|b_i|
   std::vector<float> sq(p.L), sb(p.L);

@@ -59,6 +59,16 @@ def _k_of(L: int, kfrac: float, k_floor: int) -> int:
     return min(L, max(int(k_floor), int(kfrac * L)))     # single:174 (capped at L = 8)
 
 
+def _check_password(password, what: str) -> None:
+    """The authoritative signatures (single:112-114,192) take the password as a string.  The legacy module of the
+    same name had ``extract(stego, meta, out, normalize=True)`` and ``embed(..., payload_type, text_data)`` without one
+    (core:85-92,203): a positional ``True`` from such a call site would otherwise be hashed as a password."""
+    if password is not None and not isinstance(password, str):
+        raise TypeError(f"password must be a str, got {type(password).__name__}: {what}(...) follows "
+                        "app_dct_svd_single.py's signature (password before normalize / kfrac), not the legacy "
+                        "dct_svd_core_secure.py one - pass password= and normalize= by keyword")
+
+
 def _check_tile(tile):
     if tile is not None and int(tile) != TILE:
         raise ValueError("tile must be 8 or None")
@@ -71,6 +81,7 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
                  alpha: float = 0.1, color: bool = False, kfrac: float = K_FRAC_DEFAULT,
                  tile: Optional[int] = TILE, k_floor: int = 8, device: int = 0) -> dict:
     """cover, wm: BGR uint8.  Returns dict(stego BGR uint8, meta dict, psnr, ssim)."""
+    _check_password(password, "embed")
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để nhúng.")              # single:115-116
     _check_tile(tile)
@@ -179,6 +190,7 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
                    device: int = 0) -> np.ndarray:
     """Watermark estimate (uint8 [H,W] gray / [H,W,3] colour) before the
     reference's cosmetic denoise/enhance step (single:223-227,275-277)."""
+    _check_password(password, "extract")
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để giải trích.")          # single:193-194
     mode = str(meta["mode"]); alpha = float(meta["alpha"])                 # single:196
@@ -268,6 +280,7 @@ def embed(cover_path: str, wm_source: str, out_path: str, meta_path: str,
     """single:112-190.  Returns (out_path, meta_path, psnr, ssim).  ``compress_meta=False`` writes the .npz
     uncompressed (np.load - and the reference's extract / detect - read either form): the tile-mode factors are
     float noise to zlib, and compressing the 70 MB of a 4K cover costs ten times the rest of the call."""
+    _check_password(password, "embed")
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để nhúng.")
     cover = hg.read_image_bgr(cover_path)                                  # single:117
@@ -288,6 +301,7 @@ def extract(stego_path: str, meta_path: str, out_path: str, password: str,
     """single:192-282.  ``enhance=True`` applies the unsharp half of the
     reference's cosmetic post-processing (CLAHE / NL-means are OpenCV-only and
     wrapped in try/except there); default writes the extracted plane as is."""
+    _check_password(password, "extract")
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để giải trích.")
     data = np.load(meta_path, allow_pickle=False)                          # single:195

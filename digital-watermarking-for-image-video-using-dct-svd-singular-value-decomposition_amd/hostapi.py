@@ -11,6 +11,7 @@ The error mapping mirrors what the reference's callers see
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 from typing import Optional
 
@@ -542,8 +543,14 @@ class Context:
     # The permutation is NumPy's own PCG64 shuffle (hostglue.permutation_index, bit-exact by construction);
     # its int32 copy is uploaded once per index array and kept (two entries, like the host-side cache).
     def index_dev(self, idx: np.ndarray) -> int:
+        """Device copy (int32) of a permutation index.  Cached on the index's identity: hostglue.permutation_index
+        tags its result with (H, W, sha256(key)); any other array is keyed by a digest of its contents - never by its
+        address, which NumPy reuses for the next index of the same size."""
         cache = self.__dict__.setdefault("_idx_cache", [])
-        tag = (idx.__array_interface__["data"][0], idx.size, int(idx[0]), int(idx[-1]), int(idx[idx.size // 2]))
+        tag = getattr(idx, "tag", None)
+        trusted = tag is not None                  # hostglue's own shuffle of arange: a bijection by construction
+        if tag is None:
+            tag = ("digest", idx.size, hashlib.blake2b(np.ascontiguousarray(idx).view(np.uint8), digest_size=16).digest())
         for t, d in cache:
             if t == tag:
                 return d
@@ -551,6 +558,11 @@ class Context:
             raise ValueError("plane too large for an int32 index")
         if idx.size and (int(idx.min()) < 0 or int(idx.max()) >= idx.size):
             raise ValueError("index entries must lie in [0, n)")      # the device passes gather / scatter through it unchecked
+        if not trusted and idx.size:
+            seen = np.zeros(idx.size, np.bool_)
+            seen[np.asarray(idx)] = True
+            if not seen.all():
+                raise ValueError("index is not a permutation (repeated entries): the inverse scatter would leave holes")
         i32 = np.ascontiguousarray(idx, dtype=np.int32)
         d = self.malloc(max(i32.nbytes, 4))
         self.h2d(d, i32)
@@ -640,6 +652,10 @@ class Context:
             self.extract_tiles_u8_dev(d_st, d_sc, d_u, d_v, d_w, n, H, W, W, H * W, nby * nbx if per_plane else 0,
                                       float(alpha), int(K))
             out = self._unpermute_normalize_dev(d_w, n, H, W, idx, normalize)
+            # the *_dev entry points only set the sticky status bit; without this a Jacobi that hit its sweep
+            # bound would hand back a watermark silently and surface in some later, unrelated call (DESIGN 5:
+            # non-convergence -> WM_ERR_NOCONV -> numpy.linalg.LinAlgError, like the host-pointer wrapper)
+            self.check_status()
         finally:
             for b in bufs:
                 self.free(b)

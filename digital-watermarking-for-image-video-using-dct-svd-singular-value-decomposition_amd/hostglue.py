@@ -165,6 +165,16 @@ def rng_from_key(key: bytes) -> np.random.Generator:
     return np.random.default_rng(int.from_bytes(key[:8], "big", signed=False))
 
 
+class KeyedIndex(np.ndarray):
+    """The permutation of one (H, W, key), carrying that identity as ``tag`` so that a device-side copy can be cached
+    on WHAT the index is rather than on where it lives (NumPy hands a freed index's address to the next arange of the
+    same size).  Views and copies made from it do not inherit the tag."""
+    tag = None
+
+    def __array_finalize__(self, obj):
+        self.tag = None
+
+
 _perm_cache: "OrderedDict[tuple, np.ndarray]" = OrderedDict()
 _perm_lock = threading.Lock()
 _PERM_CACHE_ENTRIES = 2
@@ -183,6 +193,8 @@ def permutation_index(H: int, W: int, key: bytes) -> np.ndarray:
             return idx
     idx = np.arange(H * W)
     rng_from_key(key).shuffle(idx)
+    idx = idx.view(KeyedIndex)
+    idx.tag = ("perm", int(H), int(W), hashlib.sha256(bytes(key)).digest())
     idx.setflags(write=False)
     with _perm_lock:
         _perm_cache[k] = idx

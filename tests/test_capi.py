@@ -117,3 +117,85 @@ def test_meta_tile_and_stego_size_are_checked():
     with pytest.raises(ValueError, match="meta was written for"):
         mod["_check_stego_shape"](np.zeros((16, 24, 3), np.uint8), meta)
     mod["_check_stego_shape"](np.zeros((16, 16, 3), np.uint8), meta)
+
+
+class _FakeLib:
+    """Stands in for libwmhip.so on a box without a GPU: every entry point succeeds and writes nothing, except
+    wm_check_status, which reports the sticky status bit (set -> WM_ERR_NOCONV).  Records the calls."""
+
+    def __init__(self, status_rc=0):
+        self.status_rc = status_rc
+        self.calls = []
+        self._next = 0x1000
+
+    def wm_last_error(self):
+        return b"SVD did not converge"
+
+    def __getattr__(self, name):
+        if not name.startswith("wm_"):
+            raise AttributeError(name)
+
+        def fn(h, *args):
+            self.calls.append(name)
+            if name == "wm_check_status":
+                return self.status_rc
+            if name == "wm_malloc":
+                self._next += 0x100000
+                args[1]._obj.value = self._next
+            return 0
+        return fn
+
+
+def _fake_ctx(hostapi, status_rc=0):
+    ctx = object.__new__(hostapi.Context)
+    ctx.lib = _FakeLib(status_rc)
+    ctx._h = None                       # close() / __del__ do nothing
+    ctx.__dict__["_h"] = 1
+    ctx.device = 0
+    return ctx
+
+
+def test_device_resident_extract_reports_a_set_status_bit(hostapi):
+    """extract_tiles_unscrambled_u8 drives the *_dev entry points, which only SET the sticky status bit: the wrapper
+    must end in wm_check_status so that a Jacobi that hit its sweep bound raises LinAlgError here, not in
+    some later unrelated call (round-2 advisor finding)."""
+    H = W = 16
+    st = np.zeros((H, W), np.uint8); sc = np.zeros((2, 2, 8), np.float32)
+    U = np.zeros((2, 2, 8, 8), np.float32)
+    idx = np.arange(H * W)
+    ctx = _fake_ctx(hostapi, status_rc=hostapi.WM_ERR_NOCONV)
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.extract_tiles_unscrambled_u8(st, sc, U, U, 0.1, 8, idx)
+    calls = ctx.lib.calls
+    assert "wm_check_status" in calls and calls.index("wm_check_status") > calls.index("wm_extract_tiles_u8_dev")
+    assert calls.count("wm_free") == calls.count("wm_malloc") - 1          # everything but the cached index is released
+    ok = _fake_ctx(hostapi, status_rc=0)
+    out = ok.extract_tiles_unscrambled_u8(st, sc, U, U, 0.1, 8, idx)
+    assert out.shape == (H, W) and out.dtype == np.uint8
+    ctx.__dict__["_h"] = None; ok.__dict__["_h"] = None
+
+
+def test_device_index_cache_is_keyed_by_identity_not_address(hostapi):
+    """The device copy of a permutation is cached on what the index IS - (H, W, sha256(key)) for
+    hostglue.permutation_index, a content digest otherwise - never on its address (NumPy reuses a freed index's
+    address for the next arange of the same size).  Non-bijective indices are refused before the upload."""
+    import importlib
+    hg = importlib.import_module(ge.PKG_NAME + ".hostglue")
+    ctx = _fake_ctx(hostapi)
+    a = hg.permutation_index(8, 8, b"k" * 32)
+    assert a.tag == ("perm", 8, 8, __import__("hashlib").sha256(b"k" * 32).digest()) and a[::2].tag is None
+    d1 = ctx.index_dev(a)
+    assert ctx.index_dev(a) == d1 and ctx.lib.calls.count("wm_malloc") == 1
+    b = hg.permutation_index(8, 8, b"q" * 32)
+    assert ctx.index_dev(b) != d1
+    # same contents at a different address: one device copy; different contents in the SAME buffer: another
+    x = np.arange(64)[::-1].copy()
+    dx = ctx.index_dev(x)
+    assert ctx.index_dev(x.copy()) == dx
+    x[0], x[1] = x[1], x[0]
+    assert ctx.index_dev(x) != dx
+    with pytest.raises(ValueError):
+        ctx.index_dev(np.zeros(16, np.int64))                   # in range, but not a permutation
+    with pytest.raises(ValueError):
+        ctx.index_dev(np.arange(16) + 1)
+    ctx.__dict__["_h"] = None

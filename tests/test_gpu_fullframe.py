@@ -255,7 +255,10 @@ def test_fullframe_cfg2_1080p_against_float64_lapack(gpu_ctx):
     assert np.abs(w - wo).max() < 2e-3 * np.abs(wo).max()
     # the watermark-side decomposition at full size (once per watermark in the product)
     U, S, Vt = gpu_ctx.ref_svd(wys, apply_dct=True)
-    assert np.max(np.abs(S - ref["Sw"])) / ref["Sw"][0] < 1e-4
+    print(f"[ff] 1080p watermark-side SVD: sigma max {np.max(np.abs(S - ref['Sw'])) / ref['Sw'][0]:.2e} * sigma_1, "
+          f"per value {np.max(np.abs(S - ref['Sw']) / ref['Sw']):.2e}")
+    # measured on the input since round 3 (|b_i| / |q_i| alone was 3e-5 relative low on every value at this size)
+    assert np.max(np.abs(S - ref["Sw"])) / ref["Sw"][0] < 2e-6 and np.max(np.abs(S - ref["Sw"]) / ref["Sw"]) < 2e-5
     L = min(H, W)
     assert np.abs(U.T @ U - np.eye(L)).max() < 2e-4 and np.abs(Vt @ Vt.T - np.eye(L)).max() < 2e-4
 

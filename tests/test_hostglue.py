@@ -115,3 +115,22 @@ def test_resize_cache_returns_the_same_pixels_and_tracks_content():
     assert b is not a and np.array_equal(b, hg.resize_area(wm2, 100, 60))
     assert not a.flags.writeable
     assert np.array_equal(hg.resize_area_cached(wm, 60, 100), hg.resize_area(wm, 60, 100))   # other size: its own entry
+
+
+def test_non_string_password_is_a_type_error_not_a_key():
+    """The legacy module of the same name had extract(stego, meta, out, normalize=True) without a password
+    (dct_svd_core_secure.py:203 of the reference): a positional True from such a call site must not be hashed
+    as a password.  Checked before anything touches a file or the GPU."""
+    import importlib
+    import pytest
+    m = importlib.import_module("dct_svd_core_secure")
+    with pytest.raises(TypeError, match="password must be a str"):
+        m.extract("stego.png", "meta.npz", "out.png", True)
+    with pytest.raises(TypeError, match="password must be a str"):
+        m.embed("cover.png", "wm.png", "out.png", "meta.npz", 0.05, False, 7)
+    with pytest.raises(TypeError):
+        m.embed_arrays(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8), b"bytes", bytes(8))
+    with pytest.raises(ValueError):                      # the reference's own check is unchanged (single:115-116)
+        m.embed("cover.png", "wm.png", "out.png", "meta.npz", password="")
+    with pytest.raises(ValueError):
+        m.extract("stego.png", "meta.npz", "out.png", None)

@@ -402,12 +402,29 @@ def render_v():
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser(description="Generate the gfx950 Jacobi instruction streams (csrc/wm_jacobi*_gfx950.inc). "
+                                 "Default: compare with the committed files and write nothing.")
+    ap.add_argument("--write", action="store_true", help="rewrite a file whose content differs (an identical file is "
+                    "never touched: its mtime would otherwise make build() recompile libwmhip.so)")
+    ap.add_argument("--check", action="store_true", help="compare only (the default); exit status 1 on a difference")
+    args = ap.parse_args()
+    differs = False
     for name, fn in (("wm_jacobi_gfx950.inc", render), ("wm_jacobi_v_gfx950.inc", render_v)):
         st, body = fn()
         out = csrc_path(name)
-        open(out, "w").write(body)
-        print(f"wrote {os.path.normpath(out)}: {n_instructions(st)} instructions, {st.nops()} s_nop", file=sys.stderr)
+        old = open(out).read() if os.path.exists(out) else None
+        what = f"{os.path.normpath(out)}: {n_instructions(st)} instructions, {st.nops()} s_nop"
+        if old == body:
+            print("up to date  " + what, file=sys.stderr)
+        elif args.write and not args.check:
+            open(out, "w").write(body)
+            print("wrote       " + what, file=sys.stderr)
+        else:
+            differs = True
+            print("DIFFERS     " + what + "   (run with --write to regenerate)", file=sys.stderr)
+    return 1 if differs else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
