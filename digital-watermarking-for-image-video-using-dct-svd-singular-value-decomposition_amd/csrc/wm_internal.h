@@ -44,6 +44,8 @@ struct wm_ctx {
   size_t ref_ws_bytes = 0;
   void* ref_ws2 = nullptr;        // second one: null-space completion of rank-deficient planes
   size_t ref_ws2_bytes = 0;
+  void* route_tmp = nullptr;      // grow-only staging of the routed unscramble (wm_route.hip): bucket-major bytes + min-max pairs
+  size_t route_tmp_bytes = 0;
   static constexpr int MAX_PAIR_TABS = 6;   // round-robin tournaments of the block Jacobi, by block count
   void* pair_tab[MAX_PAIR_TABS] = {};
   int pair_tab_nbk[MAX_PAIR_TABS] = {};
@@ -70,4 +72,37 @@ inline int use_ctx(const wm_ctx* ctx) {
 }
 // grow-only device buffer (synchronises the stream before freeing the old one)
 int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what);
+
+// ---- min-max normalise + clip + uint8 (single:221-222), shared by wm_pixel.hip and wm_route.hip ----
+__device__ __forceinline__ unsigned f2ord(float f) {   // order-preserving float -> uint
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+// block-wide min / max of order-preserving uints (any block size up to 1024); ends in a barrier, every thread
+// returns with the block's values
+__device__ __forceinline__ void block_minmax(unsigned& lo, unsigned& hi) {
+  __shared__ unsigned s_lo[16], s_hi[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_down(lo, o, 64)); hi = max(hi, __shfl_down(hi, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  const int nw = (blockDim.x + 63) >> 6;
+  lo = s_lo[0]; hi = s_hi[0];
+  for (int w = 1; w < nw; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+}
+// cv2.normalize(x, None, 0, 255, NORM_MINMAX) followed by clip + truncate; do_norm == 0: clip + truncate only
+struct NormQ {
+  float lo, scale; int do_norm;
+  __device__ NormQ(float lo_, float hi_, int dn) : lo(lo_), do_norm(dn) {
+    const double range = (double)hi_ - (double)lo_;
+    scale = (dn && range > 2.220446049250313e-16) ? (float)(255.0 / range) : 0.0f;
+  }
+  __device__ __forceinline__ unsigned operator()(float v) const {
+    if (do_norm) v = (v - lo) * scale;
+    return (unsigned)fminf(fmaxf(v, 0.0f), 255.0f);
+  }
+};
 }  // namespace wmi

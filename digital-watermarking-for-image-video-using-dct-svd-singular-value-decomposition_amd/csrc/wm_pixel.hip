@@ -300,27 +300,11 @@ __global__ void k_sum_f64(const double* __restrict__ in, const size_t n, const d
 }
 
 // ---- min-max normalise + clip + uint8 (single:221-222) ------------------------------
-__device__ __forceinline__ unsigned f2ord(float f) {   // order-preserving float -> uint
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned o) {
-  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
+// f2ord / ord2f / block_minmax / NormQ: wm_internal.h (shared with the routed unscramble, wm_route.hip)
 
 // min/max in two stages without atomics: each block leaves one {lo, hi} pair in
 // mm[2*block ..]; the consumer (k_normalize_u8) folds the n_part pairs again per block.
 constexpr unsigned MINMAX_BLOCKS = 512;
-
-__device__ __forceinline__ void block_minmax(unsigned& lo, unsigned& hi) {
-  __shared__ unsigned s_lo[4], s_hi[4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_down(lo, o, 64)); hi = max(hi, __shfl_down(hi, o, 64)); }
-  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-  hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
-}
 
 __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ x, const size_t n, unsigned* __restrict__ mm) {
   unsigned lo = 0xffffffffu, hi = 0u;
@@ -347,13 +331,7 @@ __global__ __launch_bounds__(256) void k_normalize_u8(const float* __restrict__ 
     for (unsigned i = threadIdx.x; i < n_part; i += blockDim.x) { ulo = min(ulo, mm[2 * i]); uhi = max(uhi, mm[2 * i + 1]); }
     block_minmax(ulo, uhi);
   }
-  const float lo = ord2f(ulo), hi = ord2f(uhi);
-  const double range = (double)hi - (double)lo;
-  const float scale = (do_norm && range > 2.220446049250313e-16) ? (float)(255.0 / range) : 0.0f;
-  const auto q = [&](float v) -> unsigned {
-    if (do_norm) v = (v - lo) * scale;
-    return (unsigned)fminf(fmaxf(v, 0.0f), 255.0f);
-  };
+  const NormQ q(ord2f(ulo), ord2f(uhi), do_norm);
   const size_t n4 = (((uintptr_t)out & 3u) == 0) ? n / 4 : 0;     // 4 pixels per thread: one 16-byte load, one 4-byte store
   const float4* x4 = reinterpret_cast<const float4*>(x);
   unsigned* out4 = reinterpret_cast<unsigned*>(out);

@@ -789,6 +789,7 @@ int wm_destroy(wm_ctx* ctx) {
   if (ctx->fb_list) (void)hipFree(ctx->fb_list);
   if (ctx->ref_ws) (void)hipFree(ctx->ref_ws);
   if (ctx->ref_ws2) (void)hipFree(ctx->ref_ws2);
+  if (ctx->route_tmp) (void)hipFree(ctx->route_tmp);
   for (int i = 0; i < wm_ctx::MAX_PAIR_TABS; ++i) if (ctx->pair_tab[i]) (void)hipFree(ctx->pair_tab[i]);
   for (int i = 0; i < 2; ++i) if (ctx->dct_mat[i]) (void)hipFree(ctx->dct_mat[i]);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "wm_memcpy_h2d": [_vp, _vp, _vp, _sz],
     "wm_memcpy_d2h": [_vp, _vp, _vp, _sz],
     "wm_memset": [_vp, _vp, _i, _sz],
+    "wm_copy_mapped_dev": [_vp, _vp, _vp, _sz, _i],
     "wm_event_record": [_vp, _i],
     "wm_event_elapsed_ms": [_vp, _i, _i, C.POINTER(_f)],
     "wm_embed_tiles_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
@@ -97,6 +98,10 @@ SIGNATURES = {
     "wm_permute_u8_f32_dev": [_vp, _vp, _vp, _vp, _sz, _i],
     "wm_permute_f32_dev": [_vp, _vp, _vp, _vp, _sz, _i],
     "wm_unpermute_f32_dev": [_vp, _vp, _vp, _vp, _sz, _i],
+    "wm_route_create_dev": [_vp, _vp, _sz, C.POINTER(_vp)],
+    "wm_route_destroy": [_vp, _vp],
+    "wm_unpermute_normalize_u8_dev": [_vp, _vp, _vp, _vp, _sz, _i, _i],
+    "wm_permute_u8_f32_routed_dev": [_vp, _vp, _vp, _vp, _sz, _i],
     "wm_color_u8": [_vp, _i, _vp, _vp, _vp, _vp, _sz],
     "wm_psnr_u8": [_vp, _vp, _vp, _sz, C.POINTER(C.c_double)],
     "wm_ssim": [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_double)],
@@ -185,11 +190,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            for _, d in self.__dict__.pop("_idx_cache", []):
-                try:
-                    self.free(d)
-                except Exception:
-                    pass
+            for ent in self.__dict__.pop("_idx_cache", []):
+                self._drop_index(ent)
             self.lib.wm_destroy(self._h)
             self._h = None
 
@@ -233,6 +235,10 @@ class Context:
     def d2h(self, arr: np.ndarray, dptr: int):
         assert arr.flags.c_contiguous
         self._call("wm_memcpy_d2h", _vp(arr.ctypes.data), _vp(dptr), arr.nbytes)
+
+    def copy_mapped(self, dst: int, src: int, nbytes: int, n_workgroups: int = 0):
+        """async copy kernel between device memory and mapped pinned host memory (either direction) on this stream"""
+        self._call("wm_copy_mapped_dev", _vp(dst), _vp(src), nbytes, n_workgroups)
 
     def memset(self, dptr: int, value: int, nbytes: int):
         self._call("wm_memset", _vp(dptr), value, nbytes)
@@ -542,7 +548,17 @@ class Context:
     # ---- keyed scramble / unscramble on the device (single:66-80) ------------------
     # The permutation is NumPy's own PCG64 shuffle (hostglue.permutation_index, bit-exact by construction);
     # its int32 copy is uploaded once per index array and kept (two entries, like the host-side cache).
-    def index_dev(self, idx: np.ndarray) -> int:
+    ROUTE_MAX_N = 2048 << 15        # wm_route: at most 2048 blocks of 32768 elements (67 M pixels, an 8K x 8K plane)
+
+    def _drop_index(self, ent):
+        try:
+            if ent.get("route"):
+                self.lib.wm_route_destroy(self._h, _vp(ent["route"]))
+            self.free(ent["d"])
+        except Exception:
+            pass
+
+    def _index_entry(self, idx: np.ndarray) -> dict:
         """Device copy (int32) of a permutation index.  Cached on the index's identity: hostglue.permutation_index
         tags its result with (H, W, sha256(key)); any other array is keyed by a digest of its contents - never by its
         address, which NumPy reuses for the next index of the same size."""
@@ -551,9 +567,9 @@ class Context:
         trusted = tag is not None                  # hostglue's own shuffle of arange: a bijection by construction
         if tag is None:
             tag = ("digest", idx.size, hashlib.blake2b(np.ascontiguousarray(idx).view(np.uint8), digest_size=16).digest())
-        for t, d in cache:
-            if t == tag:
-                return d
+        for ent in cache:
+            if ent["tag"] == tag:
+                return ent
         if idx.size > 0x7fffffff:
             raise ValueError("plane too large for an int32 index")
         if idx.size and (int(idx.min()) < 0 or int(idx.max()) >= idx.size):
@@ -566,12 +582,26 @@ class Context:
         i32 = np.ascontiguousarray(idx, dtype=np.int32)
         d = self.malloc(max(i32.nbytes, 4))
         self.h2d(d, i32)
-        cache.append((tag, d))
+        ent = {"tag": tag, "d": d, "n": int(idx.size), "route": None}
+        cache.append(ent)
         while len(cache) > 2:
-            _, old = cache.pop(0)
+            old = cache.pop(0)
             self.sync()
-            self.free(old)
-        return d
+            self._drop_index(old)
+        return ent
+
+    def index_dev(self, idx: np.ndarray) -> int:
+        return self._index_entry(idx)["d"]
+
+    def route_dev(self, idx: np.ndarray):
+        """The wm_route of this permutation (built once per key, kept with the device index), or None when the
+        plane is empty or has more elements than a route addresses."""
+        ent = self._index_entry(idx)
+        if ent["route"] is None and 0 < ent["n"] <= self.ROUTE_MAX_N:
+            r = _vp()
+            self._call("wm_route_create_dev", _vp(ent["d"]), ent["n"], C.byref(r))
+            ent["route"] = r.value
+        return ent["route"]
 
     def permute_planes(self, planes: np.ndarray, idx: np.ndarray) -> np.ndarray:
         """``flat[idx]`` of every plane (uint8 or float32 [H, W] / [n, H, W]) -> float32, like hostglue.permute."""
@@ -585,7 +615,10 @@ class Context:
         d_src = self.malloc(p.nbytes); d_dst = self.malloc(n_pl * n * 4)
         try:
             self.h2d(d_src, p)
-            if p.dtype == np.uint8:
+            route = self.route_dev(idx) if p.dtype == np.uint8 else None
+            if route is not None:          # the coalesced two-pass form (csrc/wm_route.hip), same values
+                self._call("wm_permute_u8_f32_routed_dev", _vp(d_src), _vp(route), _vp(d_dst), n, n_pl)
+            elif p.dtype == np.uint8:
                 self._call("wm_permute_u8_f32_dev", _vp(d_src), _vp(d_idx), _vp(d_dst), n, n_pl)
             elif p.dtype == np.float32:
                 self._call("wm_permute_f32_dev", _vp(d_src), _vp(d_idx), _vp(d_dst), n, n_pl)
@@ -612,15 +645,26 @@ class Context:
         return out[0] if single else out
 
     def _unpermute_normalize_dev(self, d_src: int, n_pl: int, H: int, W: int, idx: np.ndarray, normalize: bool) -> np.ndarray:
+        """d_src: float32 [n_pl][H*W] on the device -> uint8 [n_pl, H, W] on the host (single:74-80, 221-222; every plane
+        is normalised on its own, single:269-274).  Routed (coalesced two-pass) form whenever the plane fits a route."""
         n = H * W
         if idx.size != n:
             raise ValueError("index length does not match the plane")
+        out = np.empty((n_pl, H, W), np.uint8)
+        route = self.route_dev(idx)
+        if route is not None:
+            d_u8 = self.malloc(max(n_pl * n, 16))
+            try:
+                self._call("wm_unpermute_normalize_u8_dev", _vp(d_src), _vp(route), _vp(d_u8), n, n_pl, 1 if normalize else 0)
+                self.d2h(out, d_u8)
+            finally:
+                self.free(d_u8)
+            return out
         d_idx = self.index_dev(idx)
         n_pad = (n + 3) & ~3                      # the normalise kernel reads float4: every plane starts 16-byte aligned
         d_tmp = self.malloc(n_pl * n_pad * 4); d_u8 = self.malloc(n_pl * n_pad)
         try:
-            out = np.empty((n_pl, H, W), np.uint8)
-            for z in range(n_pl):      # the reference normalises every plane on its own (single:269-274)
+            for z in range(n_pl):
                 self._call("wm_unpermute_f32_dev", _vp(d_src + z * n * 4), _vp(d_idx), _vp(d_tmp + z * n_pad * 4), n, 1)
                 self._call("wm_normalize_u8_dev", _vp(d_tmp + z * n_pad * 4), n, 1 if normalize else 0,
                            _vp(d_u8 + z * n_pad))

@@ -67,6 +67,11 @@ int wm_free(wm_ctx* ctx, void* dptr);
 int wm_memcpy_h2d(wm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int wm_memcpy_d2h(wm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int wm_memset(wm_ctx* ctx, void* dst_dev, int value, size_t bytes);
+/* Copy kernel between device memory and pinned host memory that is mapped for the device (hipHostMalloc /
+ * hipHostRegister; either direction), enqueued on the context's stream without synchronising: the explicit form of the
+ * blit copy hipMemcpyAsync falls back to, for frame pipelines that keep one stream per PCIe direction busy.
+ * n_workgroups <= 0: 64. */
+int wm_copy_mapped_dev(wm_ctx* ctx, void* dst, const void* src, size_t bytes, int n_workgroups);
 
 /* HIP-event timing on the context's stream (slot 0..63) */
 int wm_event_record(wm_ctx* ctx, int slot);
@@ -284,6 +289,23 @@ int wm_normalize_u8_dev(wm_ctx* ctx, const float* x, size_t n, int do_norm, uint
 int wm_permute_u8_f32_dev(wm_ctx* ctx, const uint8_t* src, const int* idx, float* dst, size_t n, int n_planes);
 int wm_permute_f32_dev(wm_ctx* ctx, const float* src, const int* idx, float* dst, size_t n, int n_planes);
 int wm_unpermute_f32_dev(wm_ctx* ctx, const float* src, const int* idx, float* dst, size_t n, int n_planes);
+/* The end of the reference's extract in one routed, fully coalesced chain (single:74-80 `_unpermute` +
+ * single:221-222 cv2.normalize(NORM_MINMAX) / clip / uint8, per plane):
+ *     dst[p][idx[i]] = uint8(clip((src[p][i] - min src[p]) * 255 / (max src[p] - min src[p]), 0, 255))
+ * (do_norm == 0: clip + truncate only).  A random permutation of a whole plane makes the literal index pass touch one
+ * cache line per element; a wm_route factors idx ONCE per key into two block-local permutations around a block
+ * transpose, after which the per-frame work streams (csrc/wm_route.hip).  wm_route_create_dev reads the int32 index
+ * from device memory, synchronises the stream and returns WM_ERR_BADARG when idx is not a permutation of 0..n-1;
+ * the route holds 6 bytes per element of device memory until wm_route_destroy.  src [n_planes][n] float32,
+ * dst [n_planes][n] uint8, min / max per plane; bytes identical to wm_unpermute_f32_dev + wm_normalize_u8_dev. */
+typedef struct wm_route wm_route;
+int wm_route_create_dev(wm_ctx* ctx, const int* idx, size_t n, wm_route** route_out);
+int wm_route_destroy(wm_ctx* ctx, wm_route* route);
+int wm_unpermute_normalize_u8_dev(wm_ctx* ctx, const float* src, const wm_route* route, uint8_t* dst, size_t n,
+                                  int n_planes, int do_norm);
+/* the scramble direction through the same route (single:66-72, 124-126): dst[p][i] = (float) src[p][idx[i]], uint8 planes
+ * in, float32 out; values identical to wm_permute_u8_f32_dev */
+int wm_permute_u8_f32_routed_dev(wm_ctx* ctx, const uint8_t* src, const wm_route* route, float* dst, size_t n, int n_planes);
 /* host-pointer conveniences; op: 0 BGR->YCrCb, 1 YCrCb->BGR, 2 BGR->gray plane, 3 BGR->Y plane,
  * 4 replace Y (plane_in) and return BGR */
 int wm_color_u8(wm_ctx* ctx, int op, const uint8_t* in3, const uint8_t* plane_in, uint8_t* out3,

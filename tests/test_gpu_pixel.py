@@ -76,3 +76,57 @@ def test_device_scramble_and_unscramble_are_bit_identical_to_the_host_glue(gpu_c
     assert np.array_equal(gpu_ctx.permute_planes(g8, idx2), hg.permute(g8.astype(np.float32), idx2))
     with pytest.raises(ValueError):
         gpu_ctx.permute_planes(g8, idx2[:-1])
+
+
+def test_routed_unscramble_normalise_is_bit_identical_to_the_index_pass(gpu_ctx):
+    """wm_route (csrc/wm_route.hip): the random permutation factored once per key into two block-local permutations
+    around a block transpose, so that `_unpermute` + normalise + uint8 (single:74-80, 221-222) stream.  Bytes must
+    equal the literal chain - host `inv[idx] = arange; flat[inv]`, then the device normalise - for plane sizes below,
+    at and above the route's 32768-element block, odd element counts, one plane and several (per-plane min / max),
+    with and without normalisation, and straight through the C ABI against wm_unpermute_f32_dev + wm_normalize_u8_dev."""
+    import importlib
+    from conftest import PKG_NAME
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    hostapi = importlib.import_module(PKG_NAME + ".hostapi")
+    vp = hostapi._vp
+    rng = np.random.default_rng(23)
+    c = gpu_ctx
+    for (H, W, n_pl) in ((8, 8, 1), (40, 56, 2), (181, 181, 3), (128, 256, 1), (128, 257, 2), (200, 328, 3), (1080, 1920, 2), (2160, 3840, 1)):
+        n = H * W
+        idx = hg.permutation_index(H, W, hg.derive_key(f"route{H}x{W}", bytes(8)))
+        assert c.route_dev(idx) is not None
+        x = (rng.normal(20, 80, (n_pl, H, W)) * rng.uniform(0.2, 3, (n_pl, 1, 1))).astype(np.float32)
+        for norm in (True, False):
+            got = c.unpermute_normalize_u8(x, idx, norm)
+            for z in range(n_pl):
+                want = c.normalize_u8(hg.unpermute(x[z], idx), norm)
+                assert np.array_equal(got[z], want), (H, W, z, norm)
+        g8 = rng.integers(0, 256, (n_pl, H, W), dtype=np.uint8)            # the scramble direction through the same route
+        ps = c.permute_planes(g8, idx)
+        for z in range(n_pl):
+            assert np.array_equal(ps[z], hg.permute(g8[z].astype(np.float32), idx)), (H, W, z)
+        # the two device chains side by side through the C ABI (no host scatter involved)
+        d_x = c.malloc(x.nbytes); c.h2d(d_x, x)
+        n_pad = (n + 3) & ~3
+        d_t = c.malloc(n_pad * 4); d_a = c.malloc(n_pl * n); d_b = c.malloc(n_pad)
+        c._call("wm_unpermute_normalize_u8_dev", vp(d_x), vp(c.route_dev(idx)), vp(d_a), n, n_pl, 1)
+        a = np.empty((n_pl, n), np.uint8); c.d2h(a, d_a)
+        for z in range(n_pl):
+            c._call("wm_unpermute_f32_dev", vp(d_x + z * n * 4), vp(c.index_dev(idx)), vp(d_t), n, 1)
+            c._call("wm_normalize_u8_dev", vp(d_t), n, 1, vp(d_b))
+            b = np.empty(n, np.uint8); c.d2h(b, d_b)
+            assert np.array_equal(a[z], b), (H, W, z)
+        for d in (d_x, d_t, d_a, d_b):
+            c.free(d)
+    # constant plane: range 0 -> all zeros like cv2.normalize; a route refuses what is not a permutation
+    idx = hg.permutation_index(40, 56, hg.derive_key("k", bytes(8)))
+    assert not c.unpermute_normalize_u8(np.full((40, 56), 7.5, np.float32), idx, True).any()
+    bad = np.arange(40 * 56, dtype=np.int32); bad[5] = bad[6]
+    d_bad = c.malloc(bad.nbytes); c.h2d(d_bad, bad)
+    r = vp()
+    with pytest.raises(ValueError):
+        c._call("wm_route_create_dev", vp(d_bad), bad.size, __import__("ctypes").byref(r))
+    bad[5] = 40 * 56 + 3; c.h2d(d_bad, bad)
+    with pytest.raises(ValueError):
+        c._call("wm_route_create_dev", vp(d_bad), bad.size, __import__("ctypes").byref(r))
+    c.free(d_bad)

@@ -7,6 +7,6 @@ C=digital-watermarking-for-image-video-using-dct-svd-singular-value-decompositio
 mkdir -p tools/bin
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}; [ "$flags" = "$spec" ] && flags=""
-  ( /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -shared -fPIC $flags -o tools/bin/libwmhip_$name.so $C/wmhip.hip $C/wm_ref.hip $C/wm_pixel.hip && echo "built $name [$flags]" ) &
+  ( /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -shared -fPIC $flags -o tools/bin/libwmhip_$name.so $C/wmhip.hip $C/wm_ref.hip $C/wm_pixel.hip $C/wm_route.hip && echo "built $name [$flags]" ) &
 done
 wait

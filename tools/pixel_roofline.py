@@ -63,10 +63,12 @@ def main():
           "4 B in + 4 B index + 4 B scattered per px")
     timed("minmax + normalise -> u8", "k_minmax + k_normalize_u8", lambda: [call("wm_normalize_u8_dev", vp(d_f + z * n * 4), n, 1, vp(d_u8b + z * n)) for z in range(F)],
           F * n * 9.0, "4 B (minmax) + 4 B + 1 B per px, one plane per launch pair")
-    if hasattr(ctx.lib, "wm_unpermute_normalize_u8_dev"):
-        timed("unscramble+normalise fused", "k_minmax_planes + k_unpermute_normalize_u8",
-              lambda: call("wm_unpermute_normalize_u8_dev", vp(d_f), vp(d_idx), vp(d_u8b), n, F, 1), F * n * 13.0,
-              "4 B (minmax) + 4 B + 4 B index + 1 B out per px")
+    route = ctx.route_dev(idx)
+    timed("permute u8->f32 routed", "k_route_ga + k_route_gb", lambda: call("wm_permute_u8_f32_routed_dev", vp(d_u8), vp(route), vp(d_g), n, F), F * n * 9.0,
+          "algorithmic 9 B per px; the routed form moves 13 B, all coalesced")
+    timed("unscramble+normalise routed", "k_minmax_planes + k_route_p1 + k_route_p2",
+          lambda: call("wm_unpermute_normalize_u8_dev", vp(d_f), vp(route), vp(d_u8b), n, F, 1), F * n * 13.0,
+          "algorithmic: 4 B (minmax) + 4 B + 4 B index + 1 B out per px; the routed form moves 17 B, all coalesced")
     timed("bgr -> ycrcb", "k_color<0>", lambda: call("wm_bgr_to_ycrcb_u8_dev", vp(d_bgr), vp(d_bgr2), F * n), F * n * 6.0)
     timed("bgr -> y", "k_color<3>", lambda: call("wm_bgr_to_y_u8_dev", vp(d_bgr), vp(d_u8b), F * n), F * n * 4.0)
     timed("replace y (ycrcb -> bgr)", "k_color<4>", lambda: call("wm_replace_y_u8_dev", vp(d_bgr), vp(d_u8), vp(d_bgr2), F * n), F * n * 7.0)
