@@ -663,16 +663,19 @@ def main():
             if not a.quick:
                 out["cpu_baseline_pool"] = cpu_baseline_pool(frames[:16].cpu().numpy(), alpha)
                 out["cpu_baseline_reference_semantics"] = cpu_reference_semantics(frames[0].cpu().numpy(), wys_np, alpha)
-        if world == 1 and not a.quick:
-            hg = importlib.import_module(PKG + ".hostglue")
-            idx = hg.permutation_index(H, W, hg.derive_key("bench", bytes(8)))       # single:62-69, host (NumPy PCG64)
-            out["full_extract"] = full_extract_section(torch, api, ctx, dev, frames, Sw, Ux, Vxt, stego, sigma_c, wm_out, idx, alpha)
-            out["end_to_end"] = end_to_end_section(torch, api, dev, H, W, alpha, Sw, Ux, Vxt, idx)
-        if world == 1 and not a.no_fullframe and not a.quick and (H, W) == (2160, 3840):
+        skip = set(os.environ.get("WM_BENCH_SKIP", "").split(","))         # development: leave sections out
+        if world == 1 and not a.no_fullframe and not a.quick and (H, W) == (2160, 3840) and "fullframe" not in skip:
             # after the timed tile-mode region (value / ms_per_step above are untouched): the reference's own
             # full-frame semantics on BASELINE config 2's shape, with its own roofline and CPU baseline
             out["fullframe"] = fullframe_section(a, torch, dist, api, dev, rank, world, ctx, 2, 1,
                                                  cpu_sample=a.cpu_frames > 0)
+        if world == 1 and not a.quick:
+            hg = importlib.import_module(PKG + ".hostglue")
+            idx = hg.permutation_index(H, W, hg.derive_key("bench", bytes(8)))       # single:62-69, host (NumPy PCG64)
+            if "full_extract" not in skip:
+                out["full_extract"] = full_extract_section(torch, api, ctx, dev, frames, Sw, Ux, Vxt, stego, sigma_c, wm_out, idx, alpha)
+            if "end_to_end" not in skip:
+                out["end_to_end"] = end_to_end_section(torch, api, dev, H, W, alpha, Sw, Ux, Vxt, idx)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

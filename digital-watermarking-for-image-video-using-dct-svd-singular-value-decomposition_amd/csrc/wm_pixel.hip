@@ -121,34 +121,64 @@ __global__ __launch_bounds__(256) void k_color(const uint8_t* __restrict__ in3, 
 // ---- PSNR: sum of squared differences of two uint8 buffers ------------------------
 __global__ __launch_bounds__(256) void k_sqdiff_u8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
                                                   const size_t n, unsigned long long* __restrict__ out) {
+  // sum (x - y)^2 = sum x^2 + sum y^2 - 2 sum xy: three v_dot4_u32_u8 per 4 byte pairs instead of 4 x (two field
+  // extracts, subtract, multiply, add) - the byte-wise form was VALU-bound at 2.6 TB/s (profiles/r03_p_pixel_summary.json)
   unsigned long long acc = 0;
   const size_t n16 = n / 16;
+  const uint4* a4 = reinterpret_cast<const uint4*>(a);
+  const uint4* b4 = reinterpret_cast<const uint4*>(b);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
-    const uint4 x = reinterpret_cast<const uint4*>(a)[i], y = reinterpret_cast<const uint4*>(b)[i];
+    const uint4 x = a4[i], y = b4[i];
     const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
-    uint32_t s = 0;
+    uint32_t sq = 0, xy = 0;           // at most 32 x 255^2 and 16 x 255^2 per iteration
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int d = (int)((xs[w] >> (8 * k)) & 0xffu) - (int)((ys[w] >> (8 * k)) & 0xffu);
-        s += (uint32_t)(d * d);
-      }
-    acc += s;
+    for (int w = 0; w < 4; ++w) {
+      sq = __builtin_amdgcn_udot4(xs[w], xs[w], sq, false);
+      sq = __builtin_amdgcn_udot4(ys[w], ys[w], sq, false);
+      xy = __builtin_amdgcn_udot4(xs[w], ys[w], xy, false);
+    }
+    acc += sq - 2u * xy;               // >= 0: it is the sum of 16 squares
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (size_t i = n16 * 16; i < n; ++i) { const int d = (int)a[i] - (int)b[i]; acc += (unsigned)(d * d); }
+  // one partial per workgroup, summed by k_sum_u64: 8 192 same-address atomics from 8 XCDs serialised at ~18 ns each and
+  // WERE the kernel's 150 us (2.6 TB/s whatever the arithmetic or the operands' relative alignment - tools/sqdiff_offset_probe.py)
+  __shared__ unsigned long long red[4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);     // integer sum: order-independent, exact
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];      // integer sums: exact in any order
 }
 
-// ---- SSIM (single:44-57): 5 Gaussian-blurred moments per pixel ----------------------
-// 32x32 output tile per 256-thread workgroup, 42x42 halo tile in LDS, separable 11 taps.
-// tile of 64 x 32 outputs per workgroup, 5-pixel halo: 74 x 42 inputs (1.52x read amplification)
-constexpr int SH = 5, TX = 64, TY = 32, SWX = TX + 2 * SH, SWY = TY + 2 * SH;
-constexpr int SPX = SWX + 3;                      // LDS pitch of the input tiles: 77 = 13 mod 32, so the 4 rows x 16 stride-4 strips a wave reads land on distinct banks
-constexpr size_t SSIM_LDS_BYTES = (size_t)(2 * SWY * SPX + 5 * SWY * (TX + 1)) * sizeof(float);   // 80,136 B
+__global__ __launch_bounds__(256) void k_sum_u64(const unsigned long long* __restrict__ in, const unsigned n,
+                                                unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[4];
+  unsigned long long acc = 0;
+  for (unsigned i = threadIdx.x; i < n; i += 256) acc += in[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- SSIM (single:44-57) ---------------------------------------------------------------
+// mean of  (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2))  with the 11 x 11, sigma 1.5 Gaussian moments.
+// s1 and s2 only enter as their SUM, so FOUR blurred fields suffice instead of the reference's five: x, y, x^2 + y^2, xy.
+//
+// Round 3 form (65-72 us per 4K plane -> see DESIGN 7.1): one wave per workgroup, one image COLUMN per lane, the wave
+// walks down SS_R output rows.  Per input row: the row's (x, y, x^2 + y^2, xy) of the wave's 74 columns go to LDS as one
+// float4 per pixel (two rows double-buffered: one barrier of a single wave per row), every lane reads its 11 neighbours
+// (ds_read_b128, conflict free) and forms the 4 horizontal sums - 44 FMAs whose tap is an SGPR operand - into a ring of
+// the last 11 rows held in REGISTERS (the row loop is unrolled 11 times, so the ring indices are static: no moves); the
+// vertical sums of the row that just became complete are 44 more FMAs, then the SSIM quotient.  Nothing is computed
+// twice except the horizontal sums of the 10 halo rows (SS_R = 34: 1.29 x on half of the arithmetic) and nothing but
+// the input row passes through LDS (the tiled form wrote and re-read five float planes of horizontal sums).
+#ifndef WM_SSIM_ROWS
+#define WM_SSIM_ROWS 34
+#endif
+constexpr int SH = 5, SS_R = WM_SSIM_ROWS, SS_W = 64, SS_IW = SS_W + 2 * SH;   // SS_R + 10 input rows = 4 turns of the 11-row ring
 
 __device__ __forceinline__ int reflect101(int i, const int n) {
   if (n == 1) return 0;
@@ -159,132 +189,94 @@ __device__ __forceinline__ int reflect101(int i, const int n) {
 
 struct GaussTaps { float w[11]; };
 
-// Mean SSIM partial sums: the five 11-tap separable blurs (x, y, xx, yy, xy) fused in LDS.
-//   load 74 x 42 inputs -> horizontal pass (42 rows x 16 strips of 4 outputs) -> vertical pass
-//   (64 columns x 4 strips of 8 rows: every thread busy) + SSIM map -> one double per workgroup.
-template <typename TA, typename TB>
-__global__ __launch_bounds__(256) void k_ssim(const TA* __restrict__ img1, const size_t s1,
-                                             const TB* __restrict__ img2, const size_t s2, const int H,
-                                             const int W, const GaussTaps taps, double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float (*A)[SPX] = reinterpret_cast<float (*)[SPX]>(lds);
-  float (*B)[SPX] = reinterpret_cast<float (*)[SPX]>(lds + SWY * SPX);
-  float (*Hm)[SWY][TX + 1] = reinterpret_cast<float (*)[SWY][TX + 1]>(lds + 2 * SWY * SPX);   // [5][SWY][TX+1]
-  __shared__ double red[4];
-  const int t = threadIdx.x;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-  {
-    // one input column per lane, rows ly = (t >> 7) + 2 i.  All 21 + 21 loads are issued before the
-    // first LDS store (a load-store loop serialises on memory latency: 100 -> see DESIGN 7.1).
-    // Borders: one reflection suffices unless the image is smaller than the halo (general formula).
-    const int lx = t & 127;
-    if (lx < SWX) {
-      const bool tiny = (H < 2 * SH + 2) || (W < 2 * SH + 2);
-      auto refl = [&](int i, const int n) -> int {
-        if (tiny) return reflect101(i, n);
-        i = i < 0 ? -i : i;
-        return i >= n ? 2 * n - 2 - i : i;
-      };
-      // columns / rows past the image (tile overhang beyond W or H) may need a second fold; clamp the
-      // source index into range first: those outputs are masked out of the sum anyway
-      const int gx = refl(min(x0 + lx - SH, W + SH - 1), W);
-      const TA* p1 = img1 + gx;
-      const TB* p2 = img2 + gx;
-      float va[SWY / 2], vb[SWY / 2];
+#ifndef WM_SSIM_WAVES
+#define WM_SSIM_WAVES 4
+#endif
+template <typename TA, typename TB, bool TINY>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVES, WM_SSIM_WAVES))) void k_ssim(const TA* __restrict__ img1, const size_t s1,
+                                            const TB* __restrict__ img2, const size_t s2, const int H,
+                                            const int W, const GaussTaps taps, double* __restrict__ out) {
+  __shared__ float4 rowbuf[2][2 * SS_W];                 // [0, 74): the row; lanes 10..63 park their (unused) halo value behind it: no branch
+  const int lane = threadIdx.x;
+  const int x0 = blockIdx.x * SS_W, y0 = blockIdx.y * SS_R;
+  // source columns of this lane: main (x0 - 5 + lane) and, for lanes 0..9, the right halo (x0 + 59 + lane).
+  // Columns / rows past the image (tile overhang) are clamped into range first: their outputs are masked out anyway.
+  // Borders: one fold suffices unless the image is smaller than the halo (TINY: the general formula, its own instantiation
+  // so that the division it needs stays out of the row loop of every other image).
+  auto refl = [&](int i, const int n) -> int {
+    if (TINY) return reflect101(i, n);
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+  };
+  // per-lane column offsets (32 bit) next to a wave-uniform row base: the loads need no vector address arithmetic
+  const unsigned gxm = (unsigned)refl(min(x0 - SH + lane, W + SH - 1), W);
+  const unsigned gxh = (unsigned)refl(min(x0 - SH + SS_W + min(lane, 2 * SH - 1), W + SH - 1), W);   // lanes >= 10 repeat lane 9's column
+  constexpr int n_in = SS_R + 2 * SH;                    // input rows a wave walks through: a multiple of 11, so that the
+  static_assert(n_in % 11 == 0, "ring turns");            // unrolled body needs no exit (rows past the image are clamped, their outputs masked)
+  auto row_of = [&](const int ir) { return refl(min(y0 - SH + ir, H + SH - 1), H); };
+  // PF rows in flight ahead of the one being worked on (register ring with static indices, like the sums)
+  float am[11], bm[11], ah[11], bh[11];
+#define SSIM_FETCH(slot, ir)                                                               \
+  do {                                                                                     \
+    const size_t gy_ = (size_t)row_of(ir);                                                 \
+    const TA* r1_ = img1 + gy_ * s1; const TB* r2_ = img2 + gy_ * s2;                      \
+    am[slot] = (float)r1_[gxm]; bm[slot] = (float)r2_[gxm];                                \
+    ah[slot] = (float)r1_[gxh]; bh[slot] = (float)r2_[gxh];                                \
+  } while (0)
+#ifndef WM_SSIM_PREFETCH
+#define WM_SSIM_PREFETCH 3
+#endif
+  constexpr int PF = WM_SSIM_PREFETCH;                   // input rows in flight ahead of the one being worked on.  What matters is
+#pragma unroll                                           // that NOTHING in the row loop branches per lane: with the halo loads and
+  for (int r = 0; r < PF; ++r) SSIM_FETCH(r, r);         // stores under `if (lane < 10)` hipcc closed every block with vmcnt(0) and
+                                                         // the prefetch was void (68 us per 4K plane, as slow as the tiled form)
+  float ring[11][4];
+  float acc = 0.0f;
+  const float C1 = (0.01f * 255) * (0.01f * 255), C2 = (0.03f * 255) * (0.03f * 255);
+  const bool col_ok = x0 + lane < W;
+#pragma unroll 1
+  for (int base = 0; base < n_in; base += 11) {
 #pragma unroll
-      for (int i = 0; i < SWY / 2; ++i) {
-        const int ly = (t >> 7) + 2 * i;
-        const int gy = refl(min(y0 + ly - SH, H + SH - 1), H);
-        va[i] = (float)p1[(size_t)gy * s1];
-        vb[i] = (float)p2[(size_t)gy * s2];
+    for (int s = 0; s < 11; ++s) {
+      const int ir = base + s;
+      SSIM_FETCH((s + PF) % 11, ir + PF);                  // rows past n_in: clamped, never used
+      float4* rb = rowbuf[ir & 1];                         // 11 is odd: the parity of s alone flips with base
+      {
+        const float a = am[s], b = bm[s], c = ah[s], d = bh[s];
+        rb[lane] = make_float4(a, b, fmaf(a, a, b * b), a * b);
+        rb[SS_W + lane] = make_float4(c, d, fmaf(c, c, d * d), c * d);
       }
-#pragma unroll
-      for (int i = 0; i < SWY / 2; ++i) {
-        const int ly = (t >> 7) + 2 * i;
-        A[ly][lx] = va[i];
-        B[ly][lx] = vb[i];
-      }
-    }
-  }
-  __syncthreads();
-  // horizontal pass: SWY rows x 16 strips of 4 outputs, 14 loads per operand and work item.
-  // The five running sums are kept as two packed pairs (x, y), (xx, yy) and one scalar (xy):
-  // 3 instead of 5 FMAs per tap (the pass is VALU-issue-bound: 113 flop per pixel against 2 bytes).
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  for (int e = t; e < SWY * (TX / 4); e += 256) {
-    const int ly = e >> 4, lx0 = (e & 15) * 4;
-    v2f ab1[14], ab2[14];
-    float ab[14];
-#pragma unroll
-    for (int k = 0; k < 14; ++k) {
-      const float a = A[ly][lx0 + k], b = B[ly][lx0 + k];
-      ab1[k] = v2f{a, b};
-      ab2[k] = ab1[k] * ab1[k];
-      ab[k] = a * b;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-      float sxy = 0;
+      __syncthreads();                                     // one wave: orders this row's LDS writes before its reads
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
+        const float4 v = rb[lane + k];
         const float w = taps.w[k];
-        const v2f wv = {w, w};
-        s1 = __builtin_elementwise_fma(wv, ab1[j + k], s1);
-        s2 = __builtin_elementwise_fma(wv, ab2[j + k], s2);
-        sxy = fmaf(w, ab[j + k], sxy);
+        h0 = fmaf(w, v.x, h0); h1 = fmaf(w, v.y, h1); h2 = fmaf(w, v.z, h2); h3 = fmaf(w, v.w, h3);
       }
-      Hm[0][ly][lx0 + j] = s1.x; Hm[1][ly][lx0 + j] = s1.y; Hm[2][ly][lx0 + j] = s2.x;
-      Hm[3][ly][lx0 + j] = s2.y; Hm[4][ly][lx0 + j] = sxy;
-    }
-  }
-  __syncthreads();
-  // vertical pass + SSIM map: thread = (column, strip of 8 rows); planes again as (x, y), (xx, yy), xy
-  double acc = 0.0;
-  const float C1 = (0.01f * 255) * (0.01f * 255), C2 = (0.03f * 255) * (0.03f * 255);
-  {
-    const int lx = t & 63, ly0 = (t >> 6) * 8;
-    v2f m1[8], m2[8];
-    float m5[8];
-    {
-      v2f c1[18], c2[18];
-      float c5[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k) {
-        c1[k] = v2f{Hm[0][ly0 + k][lx], Hm[1][ly0 + k][lx]};
-        c2[k] = v2f{Hm[2][ly0 + k][lx], Hm[3][ly0 + k][lx]};
-        c5[k] = Hm[4][ly0 + k][lx];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v2f a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
-        float a5 = 0;
+      ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2; ring[s][3] = h3;
+      {                                                    // rows ir - 10 .. ir are in the ring: output row y0 + ir - 10
+        float m1 = 0.f, m2 = 0.f, e = 0.f, q = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
+          const int r = (s + 1 + k) % 11;                  // oldest row first; the taps are symmetric
           const float w = taps.w[k];
-          const v2f wv = {w, w};
-          a1 = __builtin_elementwise_fma(wv, c1[j + k], a1);
-          a2 = __builtin_elementwise_fma(wv, c2[j + k], a2);
-          a5 = fmaf(w, c5[j + k], a5);
+          m1 = fmaf(w, ring[r][0], m1); m2 = fmaf(w, ring[r][1], m2); e = fmaf(w, ring[r][2], e); q = fmaf(w, ring[r][3], q);
         }
-        m1[j] = a1; m2[j] = a2; m5[j] = a5;
+        const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+        const float num = (2.0f * m12 + C1) * (2.0f * (q - m12) + C2);
+        const float den = (m11 + m22 + C1) * ((e - m11 - m22) + C2) + 1e-12f;
+        const int oy = y0 + ir - 2 * SH;
+        const float v = num * __builtin_amdgcn_rcpf(den);
+        acc += (col_ok && ir >= 2 * SH && oy < H) ? v : 0.0f;                              // the first 10 rows only fill the ring
       }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (y0 + ly0 + j >= H || x0 + lx >= W) continue;
-      const float mu1 = m1[j].x, mu2 = m1[j].y;
-      const float s1q = m2[j].x - mu1 * mu1, s2q = m2[j].y - mu2 * mu2, s12 = m5[j] - mu1 * mu2;
-      const float num = (2 * mu1 * mu2 + C1) * (2 * s12 + C2);
-      const float den = (mu1 * mu1 + mu2 * mu2 + C1) * (s1q + s2q + C2) + 1e-12f;
-      acc += (double)(num / den);
-    }
   }
+#undef SSIM_FETCH
+  double accd = (double)acc;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((t & 63) == 0) red[t >> 6] = acc;
-  __syncthreads();
-  if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  for (int o = 32; o > 0; o >>= 1) accd += __shfl_down(accd, o, 64);
+  if (lane == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = accd;
 }
 
 __global__ void k_sum_f64(const double* __restrict__ in, const size_t n, const double scale,
@@ -423,10 +415,13 @@ int wm_replace_y_u8_dev(wm_ctx* ctx, const uint8_t* bgr, const uint8_t* y_new, u
 int wm_sqdiff_u8_dev(wm_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, unsigned long long* ssd_dev) {
   if (!ctx || !ssd_dev) return set_err(WM_ERR_BADARG, "NULL argument");
   WM_TRY(wmi::use_ctx(ctx));
-  WM_HIP(hipMemsetAsync(ssd_dev, 0, sizeof(unsigned long long), ctx->stream));
-  if (n == 0) return WM_OK;
+  if (n == 0) { WM_HIP(hipMemsetAsync(ssd_dev, 0, sizeof(unsigned long long), ctx->stream)); return WM_OK; }
   if (!a || !b || (((uintptr_t)a | (uintptr_t)b) & 15u)) return set_err(WM_ERR_BADARG, "buffers must be non-NULL and 16-byte aligned");
-  hipLaunchKernelGGL(k_sqdiff_u8, dim3(grid_for(n / 16 + 1)), dim3(256), 0, ctx->stream, a, b, n, ssd_dev);
+  const unsigned nblk = grid_for(n / 16 + 1);
+  WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, (size_t)nblk * sizeof(unsigned long long), "squared-difference partial sums"));
+  unsigned long long* part = (unsigned long long*)ctx->partials;
+  hipLaunchKernelGGL(k_sqdiff_u8, dim3(nblk), dim3(256), 0, ctx->stream, a, b, n, part);
+  hipLaunchKernelGGL(k_sum_u64, dim3(1), dim3(256), 0, ctx->stream, part, nblk, ssd_dev);
   WM_HIP(hipGetLastError());
   return WM_OK;
 }
@@ -437,17 +432,16 @@ int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2,
   if (!ctx || !img1 || !img2 || !ssim_dev) return set_err(WM_ERR_BADARG, "NULL argument");
   WM_TRY(wmi::use_ctx(ctx));
   if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
-  const dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY), block(256);
+  const dim3 grid((W + SS_W - 1) / SS_W, (H + SS_R - 1) / SS_R), block(64);
   const size_t nblk = (size_t)grid.x * grid.y;
   WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, (nblk + 1) * sizeof(double), "ssim partial sums"));
   double* part = (double*)ctx->partials;
   const GaussTaps taps = make_taps();
+  const bool tiny = (H < 2 * SH + 2) || (W < 2 * SH + 2);
 #define WM_LAUNCH_SSIM(TA_, TB_)                                                                              \
-  do { /* 80 KB of dynamic LDS is above the 64 KB default cap: raise it (per device, cheap) */                \
-    WM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ssim<TA_, TB_>),                              \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SSIM_LDS_BYTES));             \
-    hipLaunchKernelGGL((k_ssim<TA_, TB_>), grid, block, SSIM_LDS_BYTES, ctx->stream, (const TA_*)img1,        \
-                       stride1, (const TB_*)img2, stride2, H, W, taps, part);                                 \
+  do {                                                                                                        \
+    if (tiny) hipLaunchKernelGGL((k_ssim<TA_, TB_, true>), grid, block, 0, ctx->stream, (const TA_*)img1, stride1, (const TB_*)img2, stride2, H, W, taps, part); \
+    else hipLaunchKernelGGL((k_ssim<TA_, TB_, false>), grid, block, 0, ctx->stream, (const TA_*)img1, stride1, (const TB_*)img2, stride2, H, W, taps, part); \
   } while (0)
   switch (kind & 3) {
     case 0: WM_LAUNCH_SSIM(uint8_t, uint8_t); break;
