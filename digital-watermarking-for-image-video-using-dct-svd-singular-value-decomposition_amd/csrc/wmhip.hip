@@ -53,6 +53,8 @@ int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what) 
 namespace {
 
 constexpr int N_SUMS = 5;          // detect: sum a, b, ab, aa, bb
+constexpr unsigned FB_SUB = 64;    // embed: sub-lists per kind of flagged tile (one per lane of the fallback kernel's scan)
+constexpr unsigned FB_PAD = 32;    // ints between two sub-list counters: one 128-byte line each
 
 // The iteration every tile kernel spends its time in (B = X V by one-sided Jacobi) is a generated,
 // hand-scheduled gfx950 stream with pinned registers (tools/gen_jacobi_asm.py); -DWM_NO_ASM_JACOBI
@@ -285,30 +287,35 @@ __device__ __forceinline__ void embed_group(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom& g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status, uint32_t* __restrict__ fb_list, const uint32_t fb_last,
+    int* __restrict__ status, uint32_t* __restrict__ fb_list, int* __restrict__ fb_cnt, const uint32_t fb_cap,
     const int t, const int ty, const int tx, const size_t plane) {
   const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
 
-  // deficient tiles are appended (wave-aggregated) to one of the two fallback lists that share fb_list: the tiles for
-  // the literal chain grow from its front (count status[1]), the constant ones from its back (count status[2])
-  auto append_deficient = [&](const bool flag, const int which) {
+  // Flagged tiles are appended (wave-aggregated: one atomic per wave and kind) to one of three lists - 0: the literal
+  // chain, 1: constant tiles, 2: rank-1 tiles - each split into FB_SUB sub-lists with their own counters, a wave using
+  // sub-list (wave id % FB_SUB).  One counter per kind serialised the whole launch on content made of such tiles: 16 200
+  // same-address atomics at ~12 ns each were 189 of the fast kernel's 189 us on an all-flat 8 x 4K batch (round 3,
+  // gpurun_out/r03o).  Sub-list s of kind k: fb_list[(k * FB_SUB + s) * fb_cap ...], counter fb_cnt[(k * FB_SUB + s) * FB_PAD].
+  const unsigned fb_sub = blockIdx.x % FB_SUB;
+  auto append_kind = [&](const bool flag, const int kind) {
     const unsigned long long dmask = __builtin_amdgcn_ballot_w64(flag);
     if (dmask == 0ull) return;
     const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const unsigned leader = (unsigned)__builtin_ctzll(dmask);
+    const unsigned l = (unsigned)kind * FB_SUB + fb_sub;
     int base = 0;
-    if (lane == leader) base = atomicAdd(status + 1 + which, (int)__builtin_popcountll(dmask));
+    if (lane == leader) base = atomicAdd(fb_cnt + (size_t)l * FB_PAD, (int)__builtin_popcountll(dmask));
     base = __builtin_amdgcn_readlane(base, leader);
     if (flag) {
       const unsigned rank = (unsigned)__builtin_popcountll(dmask & ((1ull << lane) - 1ull));
-      const uint32_t slot = base + rank;
-      fb_list[which ? fb_last - slot : slot] = (uint32_t)(plane * g.n_tiles + t);
+      fb_list[(size_t)l * fb_cap + base + rank] = (uint32_t)(plane * g.n_tiles + t);
     }
   };
   wm::v2f a[4][8];
   float n2[8];
   int sweeps;
   bool cst;
+  int r1;
   {
     wm::RawTile raw;
     load_raw<ALIGNED>(host + off, g.row_stride, raw);
@@ -318,8 +325,14 @@ __device__ __forceinline__ void embed_group(
     // (the 16-word comparison only if some tile of the wave passes a two-word test: textured content pays 3 instructions)
     cst = false;
     if (__builtin_amdgcn_ballot_w64(raw.lo[0] == raw.hi[0] && raw.lo[0] == raw.hi[7]) != 0ull) cst = wm::raw_is_constant(raw);
-    if (__builtin_amdgcn_ballot_w64(!cst) == 0ull) {
-      append_deficient(true, 1);
+    // rank-1 tiles that are not constant (edges of flat rectangles, rules and their crossings): closed form as well
+    // (wm::embed_tile_rank1, third list).  The exact test (64 integer products) only runs if some tile of the wave passes
+    // three 2x2 minors: textured waves pay ~15 instructions.
+    r1 = 0;
+    if (__builtin_amdgcn_ballot_w64(!cst && wm::raw_rank1_pretest(raw)) != 0ull && !cst && wm::raw_is_rank1(raw)) r1 = 1;
+    if (__builtin_amdgcn_ballot_w64(!cst && r1 == 0) == 0ull) {      // nothing in this wave needs the iteration
+      append_kind(cst, 1);
+      append_kind(r1 != 0, 2);
       return;
     }
 #if !defined(WM_NO_ASM_JACOBI)
@@ -342,13 +355,14 @@ __device__ __forceinline__ void embed_group(
 #pragma unroll
     for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
     wm::embed_coeffs_pk(n2, sw, alpha_k, e, sc, deficient);
-    deficient = deficient || cst;              // (a constant tile always is: sigma_8 = 0)
+    deficient = deficient || cst || r1 != 0;   // (constant and rank-1 tiles always are: sigma_8 = 0)
     // flagged tiles are left untouched: stego may alias host (in-place embedding) and the
     // fallback kernel must still read the original pixels; it also writes their Sc
     if (!deficient) store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
   }
-  append_deficient(deficient && !cst, 0);
-  append_deficient(cst, 1);
+  append_kind(deficient && !cst && r1 == 0, 0);
+  append_kind(cst, 1);
+  append_kind(r1 != 0, 2);
   if (sweeps < 0) atomicOr(status, 1);
   float* ywp = YW ? yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8 : nullptr;
 #pragma nounroll
@@ -371,13 +385,14 @@ __global__ __launch_bounds__(WAVE, WM_EMBED_WAVES) void k_embed_tiles(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const unsigned n_groups, const size_t sw_plane_stride,
-    const float alpha, const int K, int* __restrict__ status, uint32_t* __restrict__ fb_list, const uint32_t fb_last) {
+    const float alpha, const int K, int* __restrict__ status, uint32_t* __restrict__ fb_list, int* __restrict__ fb_cnt,
+    const uint32_t fb_cap) {
   const unsigned w = blockIdx.x;
   const unsigned plane = w / n_groups, grp = w - plane * n_groups;
   const int t = (int)(grp * WAVE + threadIdx.x);
   if (t >= g.n_tiles) return;
   const int ty = t / g.nbx, tx = t - ty * g.nbx;
-  embed_group<ALIGNED, YW>(host, sigma_w, stego, sigma_c, yw, g, sw_plane_stride, alpha, K, status, fb_list, fb_last,
+  embed_group<ALIGNED, YW>(host, sigma_w, stego, sigma_c, yw, g, sw_plane_stride, alpha, K, status, fb_list, fb_cnt, fb_cap,
                            t, ty, tx, (size_t)plane);
 }
 
@@ -392,8 +407,7 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const uint32_t fb_last) {
-  const int count = status[1], n_const = status[2];
+    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const int* __restrict__ fb_cnt, const uint32_t fb_cap) {
   float alpha_k[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
@@ -407,8 +421,31 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
       for (int r = 0; r < 8; ++r) store_row8_f32<false>(o + (size_t)r * g.W, a[r]);
     }
   };
-  for (int it = blockIdx.x * WAVE + threadIdx.x; it < count; it += gridDim.x * WAVE) {
-    const uint32_t id = fb_list[it];
+  // item `it` of kind k: the sub-lists' counts are scanned in the wave (lane l holds sub-list l), the owning sub-list is
+  // found by a 6-step search over the lanes' prefix sums
+  static_assert(FB_SUB == WAVE, "one sub-list per lane");
+  int pre[3], total[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = fb_cnt[(size_t)(k * FB_SUB + threadIdx.x) * FB_PAD];
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) { const int v = __shfl_up(incl, o, WAVE); if ((int)threadIdx.x >= o) incl += v; }
+    pre[k] = incl - c;
+    total[k] = __shfl(incl, WAVE - 1, WAVE);
+  }
+  auto item = [&](const int k, const int it) -> uint32_t {      // `it` < total[k]
+    int s_ = 0;
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) { const int p_ = __shfl(pre[k], s_ + o, WAVE); if (p_ <= it) s_ += o; }
+    const int p0 = __shfl(pre[k], s_, WAVE);
+    return fb_list[(size_t)(k * FB_SUB + s_) * fb_cap + (it - p0)];
+  };
+  const int count = total[0], n_const = total[1], n_rank1 = total[2];
+  for (int it0 = blockIdx.x * WAVE; it0 < count; it0 += gridDim.x * WAVE) {      // wave-uniform bounds: the shuffles need every lane
+    const int it = it0 + threadIdx.x;
+    const uint32_t id = item(0, min(it, count - 1));
+    if (it >= count) continue;
     const size_t plane = id / (uint32_t)g.n_tiles;
     const int t = (int)(id % (uint32_t)g.n_tiles);
     const int ty = t / g.nbx, tx = t - ty * g.nbx;
@@ -419,8 +456,10 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
     if (wm::embed_tile_completed(a, sw, alpha_k, sc) < 0) atomicOr(status, 1);
     finish(plane, t, off, sc, a);
   }
-  for (int it = blockIdx.x * WAVE + threadIdx.x; it < n_const; it += gridDim.x * WAVE) {
-    const uint32_t id = fb_list[fb_last - (uint32_t)it];
+  for (int it0 = blockIdx.x * WAVE; it0 < n_const; it0 += gridDim.x * WAVE) {
+    const int it = it0 + threadIdx.x;
+    const uint32_t id = item(1, min(it, n_const - 1));
+    if (it >= n_const) continue;
     const size_t plane = id / (uint32_t)g.n_tiles;
     const int t = (int)(id % (uint32_t)g.n_tiles);
     const int ty = t / g.nbx, tx = t - ty * g.nbx;
@@ -434,6 +473,20 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
     if (bm == 0ull) wm::embed_tile_constant_t<1>(v0, sw, alpha_k, sc, a);
     else if (bm == __builtin_amdgcn_ballot_w64(true)) wm::embed_tile_constant_t<0>(v0, sw, alpha_k, sc, a);
     else wm::embed_tile_constant(v0, sw, alpha_k, sc, a);
+    finish(plane, t, off, sc, a);
+  }
+  for (int it0 = blockIdx.x * WAVE; it0 < n_rank1; it0 += gridDim.x * WAVE) {
+    const int it = it0 + threadIdx.x;
+    const uint32_t id = item(2, min(it, n_rank1 - 1));
+    if (it >= n_rank1) continue;
+    const size_t plane = id / (uint32_t)g.n_tiles;
+    const int t = (int)(id % (uint32_t)g.n_tiles);
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
+    const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
+    float a[8][8], sw[8], sc[8];
+    load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
+    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+    wm::embed_tile_rank1(a, sw, alpha_k, sc, a);
     finish(plane, t, off, sc, a);
   }
 }
@@ -765,8 +818,8 @@ int wm_create(int device, void* stream, wm_ctx** ctx_out) {
     if (e != hipSuccess) { delete ctx; return set_err(WM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ctx->owns_stream = true;
   }
-  hipError_t e = hipMalloc((void**)&ctx->d_status, 3 * sizeof(int));   // [0] status, [1] literal-fallback count, [2] constant-tile count
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 3 * sizeof(int), ctx->stream);
+  hipError_t e = hipMalloc((void**)&ctx->d_status, 4 * sizeof(int));   // [0] sticky kernel status (the flagged-tile counters live behind fb_list)
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_status, 0, 4 * sizeof(int), ctx->stream);
   for (int i = 0; i < N_EVENTS && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
   if (e != hipSuccess) { wm_destroy(ctx); return set_err(WM_ERR_HIP, "context setup: %s", hipGetErrorString(e)); }
   *ctx_out = ctx;
@@ -889,19 +942,25 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
     const size_t n_all = (size_t)g.n_tiles * (size_t)n_planes;
     if (n_all > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 tiles in one call");   // ids are uint32, the device-side count an int
     const size_t n_waves = (n_all + WAVE - 1) / WAVE;
-    WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, n_all * sizeof(uint32_t), "fallback list"));
-    WM_HIP(hipMemsetAsync(ctx->d_status + 1, 0, 2 * sizeof(int), ctx->stream));
+    // three kinds x FB_SUB sub-lists of fb_cap entries (a sub-list holds at most the tiles of the waves that hash to it),
+    // then the padded counters
+    const size_t cap = (n_work_sz + FB_SUB - 1) / FB_SUB * WAVE;
+    if (cap > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 tiles in one call");
+    const size_t list_bytes = (size_t)3 * FB_SUB * cap * sizeof(uint32_t), cnt_bytes = (size_t)3 * FB_SUB * FB_PAD * sizeof(int);
+    WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, list_bytes + cnt_bytes, "fallback lists"));
     uint32_t* fb = (uint32_t*)ctx->fb_list;
-    const uint32_t fb_last = (uint32_t)(n_all - 1);      // the constant tiles' list grows down from here
+    int* fb_cnt = (int*)((char*)ctx->fb_list + list_bytes);
+    WM_HIP(hipMemsetAsync(fb_cnt, 0, cnt_bytes, ctx->stream));
+    const uint32_t fb_cap = (uint32_t)cap;
     const dim3 fgrid((unsigned)(n_waves < 2048 ? n_waves : 2048));
 #define WM_LAUNCH_EMBED(A, Y)                                                                      \
   do {                                                                                             \
     hipLaunchKernelGGL((k_embed_tiles<A, Y>), grid, block, 0, ctx->stream, host, sigma_w, stego,   \
                        sigma_c, yw, g, n_groups, sigma_w_plane_stride, alpha, K,                   \
-                       ctx->d_status, fb, fb_last);                                                 \
+                       ctx->d_status, fb, fb_cnt, fb_cap);                                          \
     hipLaunchKernelGGL((k_embed_fallback<A, Y>), fgrid, block, 0, ctx->stream, host, sigma_w,      \
                        stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb,   \
-                       fb_last);                                                                   \
+                       fb_cnt, fb_cap);                                                            \
   } while (0)
     if (al && yw) WM_LAUNCH_EMBED(true, true);
     else if (al) WM_LAUNCH_EMBED(true, false);

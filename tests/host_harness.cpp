@@ -143,6 +143,7 @@ int hh_embed_tiles_u8_pk(const uint8_t* host, const float* sigma_w, uint8_t* ste
         ++nf;
         raw_to_f32(raw, y);
         if (raw_is_constant(raw)) { embed_tile_constant(y[0][0], sw, alpha_k, sc, y); s = 1; }   // like k_embed_fallback
+        else if (raw_rank1_pretest(raw) && raw_is_rank1(raw)) { embed_tile_rank1(y, sw, alpha_k, sc, y); s = 1; }   // closed form as well
         else s = embed_tile_completed(y, sw, alpha_k, sc);
         for (int r = 0; r < 8; ++r) {
           out.lo[r] = quant_u8(y[r][0]) | (quant_u8(y[r][1]) << 8) | (quant_u8(y[r][2]) << 16) | (quant_u8(y[r][3]) << 24);
@@ -187,6 +188,25 @@ void hh_constant_tile_both_ways(float v, const float* sw, const float* alpha_k, 
   for (int r = 0; r < 8; ++r) for (int c = 0; c < 8; ++c) a[r][c] = v;
   embed_tile_completed(a, swa, ak, sc);
   memcpy(yw_literal, a, sizeof(a)); memcpy(sc_literal, sc, sizeof(sc));
+}
+
+// one rank-1 tile (uint8 values in tile[64]) through the closed form and the literal chain; returns raw_is_rank1's verdict
+int hh_rank1_tile_both_ways(const uint8_t* tile, const float* sw, const float* alpha_k, float* yw_closed, float* sc_closed,
+                            float* yw_literal, float* sc_literal) {
+  float swa[8], ak[8], sc[8], a[8][8], x[8][8];
+  RawTile raw;
+  load_raw(tile, 8, raw);
+  for (int i = 0; i < 8; ++i) { swa[i] = sw[i]; ak[i] = alpha_k[i]; }
+  for (int r = 0; r < 8; ++r) for (int c = 0; c < 8; ++c) x[r][c] = (float)tile[r * 8 + c];
+  const int is1 = (raw_rank1_pretest(raw) && raw_is_rank1(raw)) ? 1 : 0;
+  if (is1) {
+    embed_tile_rank1(x, swa, ak, sc, a);
+    memcpy(yw_closed, a, sizeof(a)); memcpy(sc_closed, sc, sizeof(sc));
+  }
+  memcpy(a, x, sizeof(a));
+  embed_tile_completed(a, swa, ak, sc);
+  memcpy(yw_literal, a, sizeof(a)); memcpy(sc_literal, sc, sizeof(sc));
+  return is1;
 }
 
 void hh_dct8x8(float* tile, int inverse) {

@@ -182,6 +182,62 @@ def test_constant_tiles_take_the_closed_form(gpu_ctx):
     assert np.array_equal(buf, stego) and np.array_equal(sc_ip.reshape(sc.shape), sc)
 
 
+def test_rank1_tiles_take_the_closed_form(gpu_ctx):
+    """Screen-like content: rank-1 tiles - rows all equal (vertical edges and rules), columns all equal (horizontal
+    ones), rule crossings on a flat background - are finished by wm::embed_tile_rank1 (third list of the fast kernel)
+    whether a whole wave is made of such tiles and constant ones (the iteration is skipped) or they sit among textured tiles.  Device = CPU build of the same
+    arithmetic up to the reciprocal square root (v_rsq_f32 against 1 / sqrtf: Yw within 1e-3), Sc = (sigma_1, 0, ..) with
+    exact zeros, the reference's invariant svd(Yw) = Sc + alpha Sw, independence from the other tiles, in-place embedding."""
+    import ctypes as C
+    import __graft_entry__ as ge
+    hh = C.CDLL(ge.build_host_harness())
+    vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(78)
+    H, W = 128, 1024                                             # 128 tiles per row: two waves per tile row
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[:32] = 240                                               # flat background ...
+    img[:32, 100:103] = 0; img[:32, 517] = 30                    # ... with vertical rules: rows-equal tiles among constant ones (whole waves)
+    img[12] = 0; img[27, :512] = 240 - 90                        # horizontal rules: columns-equal tiles; the crossings with the black rule are rank 1 too
+    img[64:72, 256:512] = np.repeat(rng.integers(0, 256, (1, 256), dtype=np.uint8), 8, axis=0)    # rows-equal strip inside texture (mixed waves)
+    img[80:96, 600:640] = np.repeat(rng.integers(0, 256, (16, 1), dtype=np.uint8), 40, axis=1)    # columns-equal patch inside texture
+    nby, nbx = H // 8, W // 8
+    sw = np.sort(rng.uniform(1, 1500, (nby, nbx, 8)).astype(np.float32), axis=-1)[..., ::-1].copy()
+    stego, sc, yw = gpu_ctx.embed_tiles(img, sw, 0.15, want_yw=True)
+    st_h = np.empty_like(img); sc_h = np.empty((nby * nbx, 8), np.float32); yw_h = np.empty((H, W), np.float32)
+    ms = C.c_int(0); nf = C.c_int(0)
+    hh.hh_embed_tiles_u8_pk(vp(img), vp(sw), vp(st_h), vp(sc_h), vp(yw_h), H, W, W, C.c_float(0.15), 8, C.byref(ms), C.byref(nf))
+    T = lambda x: x.reshape(nby, 8, nbx, 8).transpose(0, 2, 1, 3)
+    tiles = T(img)
+    rows_eq = (tiles == tiles[:, :, :1, :]).all(axis=(2, 3)); cols_eq = (tiles == tiles[:, :, :, :1]).all(axis=(2, 3))
+    rk = np.linalg.matrix_rank(tiles.astype(np.float64))
+    r1 = (rk == 1) & ~(rows_eq & cols_eq)
+    assert rows_eq[8].sum() == 32 and cols_eq[10:12, 75:80].all() and r1.sum() > 150
+    assert (r1 & ~rows_eq & ~cols_eq).sum() >= 1                 # a crossing: rank 1 with neither rows nor columns equal
+    assert np.abs(T(yw)[r1] - T(yw_h)[r1]).max() < 1e-3
+    assert np.abs(sc[r1][:, 0] - sc_h.reshape(nby, nbx, 8)[r1][:, 0]).max() < 1e-3 and not sc[r1][:, 1:].any()
+    X = tiles[r1].astype(np.float64)
+    assert np.abs(sc[r1][:, 0] - np.linalg.svd(X, compute_uv=False)[:, 0]).max() < 1e-3
+    got = np.linalg.svd(T(yw)[r1].astype(np.float64), compute_uv=False)
+    want = np.sort(sc[r1].astype(np.float64) + 0.15 * sw[r1], axis=-1)[:, ::-1]
+    assert np.max(np.abs(got - want) / np.maximum(want[:, :1], 1.0)) < 2e-5
+    assert np.array_equal(stego, np.clip(yw, 0, 255).astype(np.uint8))
+    # every other tile: as in the CPU build (full-rank ones to 1 LSB; constant ones bit for bit)
+    full = np.linalg.matrix_rank(tiles.astype(np.float64)) == 8
+    d = np.abs(T(stego).astype(int) - T(st_h).astype(int))[full]
+    assert full.sum() > 1000 and d.max() <= 1 and np.mean(d != 0) < 1e-3
+    const = rows_eq & cols_eq
+    assert const.sum() > 300 and np.array_equal(T(yw)[const], T(yw_h)[const])
+    # the textured tiles do not care what the structured rows hold, and a rank-1 tile does not care about its neighbours
+    img2 = img.copy(); img2[32:64] = rng.integers(0, 256, (32, W), dtype=np.uint8)
+    stego2, _, yw2 = gpu_ctx.embed_tiles(img2, sw, 0.15, want_yw=True)
+    assert np.array_equal(stego2[:32], stego[:32]) and np.array_equal(yw2[64:], yw[64:])
+    # in place
+    buf = img.copy(); sc_ip = np.empty((nby * nbx, 8), np.float32)
+    cp = lambda a_: C.c_void_p(a_.ctypes.data)
+    gpu_ctx._call("wm_embed_tiles_u8", cp(buf), cp(sw), cp(buf), cp(sc_ip), None, 1, H, W, W, H * W, 0, 0.15, 8)
+    assert np.array_equal(buf, stego) and np.array_equal(sc_ip.reshape(sc.shape), sc)
+
+
 def test_unaligned_and_strided_planes(gpu_ctx, hostapi):
     """Byte-wise kernel variants: row stride / base address not multiples of 8,
     planes embedded in a larger buffer (row_stride > W, plane_stride > H*row_stride)."""

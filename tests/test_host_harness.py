@@ -245,3 +245,70 @@ int main() {
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-2000:]
+
+
+def test_rank1_closed_form(hh):
+    """embed_tile_rank1 (csrc/wm_tile_math.h): rank-1 tiles X = a b^T (edges of flat rectangles, rules and their
+    crossings, one-axis gradients) are finished analytically with two Householder reflections instead of the Jacobi
+    with V.  LAPACK's completion of the seven null directions is arbitrary, so pixels are not comparable with the oracle;
+    what the reference guarantees whatever the completion is (single:174-176): svd(Yw) = Sc + alpha Sw with Sc the tile's
+    true singular values, and the injected energy alpha |Sw[:K]|.  The literal chain agrees on both.  raw_is_rank1 decides
+    exactly on the integers: rank-2 tiles and full-rank tiles are refused, the zero tile too (it is a constant tile)."""
+    rng = np.random.default_rng(11)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+    ones = np.ones(8)
+    edge = np.array([10, 10, 10, 200, 200, 200, 200, 200.0])
+    line = np.array([1, 1, 1, 0, 1, 1, 1, 1.0])
+    tiles = [np.outer(ones, edge), np.outer(edge, ones), np.outer(ones, [0, 0, 0, 0, 255, 0, 0, 0]), np.outer([255, 0, 0, 0, 0, 0, 0, 0], ones),
+             240 * np.outer(line, np.roll(line, 3)),                       # a rule crossing on a flat background: rank 1, no equal rows / columns
+             np.outer([1, 2, 3, 4, 5, 6, 7, 8], [30, 20, 10, 5, 0, 1, 2, 3]), np.outer(np.arange(8), np.arange(8)) * 5,
+             np.zeros((8, 8)) + np.eye(8)[0][:, None] * np.eye(8)[7][None, :] * 3, np.full((8, 8), 77.0)]
+    for X in tiles:
+        for K in (8, 3):
+            sw = f32(np.sort(rng.uniform(1, 2000, 8))[::-1]); ak = f32([0.15 if i < K else 0 for i in range(8)])
+            yc = np.empty((8, 8), np.float32); sc_c = np.empty(8, np.float32); yl = np.empty((8, 8), np.float32); sc_l = np.empty(8, np.float32)
+            assert hh.hh_rank1_tile_both_ways(vp(u8(X)), vp(sw), vp(ak), vp(yc), vp(sc_c), vp(yl), vp(sc_l)) == 1
+            s_true = np.linalg.svd(X, compute_uv=False)
+            assert abs(sc_c[0] - s_true[0]) < 2e-6 * s_true[0] and not sc_c[1:].any()
+            w = (ak * sw).astype(np.float64)
+            want = np.sort(sc_c.astype(np.float64) + w)[::-1]
+            got = np.linalg.svd(yc.astype(np.float64), compute_uv=False)
+            assert np.abs(got - want).max() < 2e-5 * max(want[0], 1.0), (X, K)
+            inj = np.sqrt(((yc - X) ** 2).sum())
+            assert abs(inj - np.sqrt((w ** 2).sum())) < 1e-4 * inj
+            # the literal chain agrees on what is defined: Sc (up to its delta-sized completion values), the energy
+            assert abs(sc_l[0] - sc_c[0]) < 1e-5 * sc_c[0] + 1e-3 and sc_l[1:].max() < 4 * 2.0 ** -14 + 1e-6 * sc_c[0]
+            assert abs(np.sqrt(((yl - X) ** 2).sum()) - inj) < 2e-3 * inj
+    dummy = [np.empty((8, 8), np.float32), np.empty(8, np.float32), np.empty((8, 8), np.float32), np.empty(8, np.float32)]
+    sw = f32(np.arange(8, 0, -1)); ak = f32([0.15] * 8)
+    rank2 = np.outer(ones, edge) + np.outer([0, 0, 0, 5, 5, 5, 5, 5], ones)
+    off_by_one = np.outer([1, 2, 3, 4, 5, 6, 7, 8], [30, 20, 10, 5, 0, 1, 2, 3]); off_by_one[5, 2] += 1
+    for X in (rank2, off_by_one, rng.integers(0, 256, (8, 8)), np.zeros((8, 8)), np.eye(8) * 9):
+        assert hh.hh_rank1_tile_both_ways(vp(u8(X)), vp(sw), vp(ak), *[vp(d) for d in dummy]) == 0
+
+
+def test_rank1_tiles_take_the_closed_form_in_the_plane_path(hh):
+    """hh_embed_tiles_u8_pk (the CPU mirror of k_embed_tiles + k_embed_fallback) routes constant tiles and rank-1 tiles
+    to their closed forms and everything else that is rank deficient to the literal chain; the completion properties
+    hold on all of them."""
+    img, mask = _degenerate_image()
+    img[8:24, 40:52] = 17; img[8:24, 52:64] = 230                  # a vertical edge inside the tiles of columns 48..55: rows-equal tiles
+    img[40:44, 64:96] = 5; img[44:48, 64:96] = 250                 # a horizontal edge: columns-equal tiles
+    mask[8:24, 40:64] = True; mask[40:48, 64:96] = True
+    H, W = img.shape
+    wys = np.random.default_rng(4321).integers(0, 256, (H, W)).astype(np.float32)
+    ref = o.embed_plane(img.astype(np.float32), wys, 0.15, 0.6, 8)
+    nb = (H // 8) * (W // 8)
+    sw = np.ascontiguousarray(ref["Sw"].reshape(nb, 8))
+    stego = np.empty((H, W), np.uint8); sc = np.empty((nb, 8), np.float32); yw = np.empty((H, W), np.float32)
+    ms = C.c_int(0); nf = C.c_int(0)
+    hh.hh_embed_tiles_u8_pk(vp(img), vp(sw), vp(stego), vp(sc), vp(yw), H, W, W, C.c_float(0.15), 8, C.byref(ms), C.byref(nf))
+    check_completion_properties(img, mask, wys, 0.15, stego, sc, yw, ref)
+    tiles = img.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3)
+    rows_eq = (tiles == tiles[:, :, :1, :]).all(axis=(2, 3)); cols_eq = (tiles == tiles[:, :, :, :1]).all(axis=(2, 3))
+    r1 = (rows_eq | cols_eq) & ~(rows_eq & cols_eq)
+    assert r1.sum() >= 16 + 2 + 4                                  # the rank-1 block of _degenerate_image + the two edges
+    assert not sc.reshape(H // 8, W // 8, 8)[r1][:, 1:].any()      # closed form: exact zeros, not the pattern's delta-sized values
+    rank2 = np.zeros_like(r1); rank2[12:, 4:8] = True              # _degenerate_image's rank-2 block: the literal chain, delta-sized values
+    assert (sc.reshape(H // 8, W // 8, 8)[rank2][:, 2:] > 0).all()
