@@ -76,6 +76,7 @@ def main():
             wave_instr_per_s=e["SQ_INSTS_VALU"] / (e["avg_us_kernel_trace"] * 1e-6))
         json.dump(dict(hbm_bytes_per_launch_at_bench_shape=fetch_b + write_b,
                        frames_per_launch=F, H=H, W=W, source=f"profiles/{tag}_summary.json",
+                       measured=__import__("datetime").date.today().isoformat(),
                        valu_busy_fraction=out["embed"]["valu_busy_fraction"],
                        effective_clock_GHz=out["embed"]["effective_clock_GHz"],
                        valu_insts_per_wave=out["embed"]["valu_insts_per_wave"]),
