@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--mode", choices=("tile", "fullframe"), default="tile",
                     help="tile: the 8x8 hot path (contract default); fullframe: the reference's own "
                          "semantics (one dense SVD per plane), secondary workload")
-    ap.add_argument("--ff-frames", type=int, default=8, help="full-frame section: planes per rank per step")
+    ap.add_argument("--ff-frames", type=int, default=16, help="full-frame section: planes per rank per step")
     ap.add_argument("--ff-height", type=int, default=1080)
     ap.add_argument("--ff-width", type=int, default=1920)
     ap.add_argument("--no-fullframe", action="store_true", help="skip the full-frame section of the default line")

@@ -67,6 +67,21 @@ int main(int argc, char** argv) {
             a[l][rp][c] = v;
           }
           col_norms2_pk(a[l], n2[l]); tile_done[l] = 0;
+          if (argc > 1 && atoi(argv[1]) == 1) {      // experiment: columns sorted by norm (descending) before the first sweep
+            int ord[8]; for (int c = 0; c < 8; ++c) ord[c] = c;
+            std::sort(ord, ord + 8, [&](int u, int v) { return n2[l][u] > n2[l][v]; });
+            v2f b[4][8]; float m2[8];
+            for (int c = 0; c < 8; ++c) { for (int rp = 0; rp < 4; ++rp) b[rp][c] = a[l][rp][ord[c]]; m2[c] = n2[l][ord[c]]; }
+            for (int c = 0; c < 8; ++c) { for (int rp = 0; rp < 4; ++rp) a[l][rp][c] = b[rp][c]; n2[l][c] = m2[c]; }
+          }
+          if (argc > 1 && atoi(argv[1]) == 2) {      // experiment: the ROWS' mean removed first?  (no: changes the matrix) - transpose instead
+            v2f b[4][8];
+            float t_[8][8];
+            for (int rp = 0; rp < 4; ++rp) for (int c = 0; c < 8; ++c) { t_[2 * rp][c] = a[l][rp][c][0]; t_[2 * rp + 1][c] = a[l][rp][c][1]; }
+            for (int rp = 0; rp < 4; ++rp) for (int c = 0; c < 8; ++c) { v2f v = {t_[c][2 * rp], t_[c][2 * rp + 1]}; b[rp][c] = v; }
+            for (int rp = 0; rp < 4; ++rp) for (int c = 0; c < 8; ++c) a[l][rp][c] = b[rp][c];
+            col_norms2_pk(a[l], n2[l]);
+          }
         }
         int sweep = 0; bool more = true;
         while (more && sweep < 12) {
