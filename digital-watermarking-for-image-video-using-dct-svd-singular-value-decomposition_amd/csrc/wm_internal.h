@@ -46,6 +46,8 @@ struct wm_ctx {
   size_t ref_ws2_bytes = 0;
   void* route_tmp = nullptr;      // grow-only staging of the routed unscramble (wm_route.hip): bucket-major bytes + min-max pairs
   size_t route_tmp_bytes = 0;
+  void* extract_f32 = nullptr;    // grow-only float estimate + min-max partials of wm_extract_unscrambled_u8_dev
+  size_t extract_f32_bytes = 0;
   static constexpr int MAX_PAIR_TABS = 6;   // round-robin tournaments of the block Jacobi, by block count
   void* pair_tab[MAX_PAIR_TABS] = {};
   int pair_tab_nbk[MAX_PAIR_TABS] = {};
@@ -72,6 +74,10 @@ inline int use_ctx(const wm_ctx* ctx) {
 }
 // grow-only device buffer (synchronises the stream before freeing the old one)
 int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what);
+// wm_route.hip: routed unscramble + normalise; mm_ext != NULL: n_part_ext {min, max} pairs per plane already on the device
+// (order-preserving uint form), include_zero: the value 0 also takes part in the min / max
+int route_unpermute_normalize(wm_ctx* ctx, const float* src, const wm_route* r, uint8_t* dst, size_t n, int n_planes, int do_norm,
+                              const unsigned* mm_ext, unsigned n_part_ext, int include_zero);
 
 // ---- min-max normalise + clip + uint8 (single:221-222), shared by wm_pixel.hip and wm_route.hip ----
 __device__ __forceinline__ unsigned f2ord(float f) {   // order-preserving float -> uint

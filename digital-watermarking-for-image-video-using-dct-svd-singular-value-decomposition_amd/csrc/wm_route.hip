@@ -117,7 +117,8 @@ __global__ __launch_bounds__(ROUTE_NT) void k_route_p1(const float* __restrict__
                                                       const int nb, const uint16_t* __restrict__ l1,
                                                       const uint16_t* __restrict__ bkt, const uint32_t* __restrict__ lrs,
                                                       const uint32_t* __restrict__ cstart, const unsigned* __restrict__ mm,
-                                                      const unsigned n_part, const int do_norm, uint8_t* __restrict__ tmp) {
+                                                      const unsigned n_part, const int do_norm, const int include_zero,
+                                                      uint8_t* __restrict__ tmp) {
   extern __shared__ uint32_t smem[];         // lrs row [nb + 1] | cstart row [nb] | bytes [S]
   uint32_t* lr = smem; uint32_t* cs = smem + nb + 1;
   uint8_t* val = reinterpret_cast<uint8_t*>(smem + 2 * nb + 2);
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(ROUTE_NT) void k_route_p1(const float* __restrict__
   unsigned ulo = 0xffffffffu, uhi = 0u;
   if (do_norm) {
     for (unsigned i = threadIdx.x; i < n_part; i += ROUTE_NT) { ulo = min(ulo, mm[2 * i]); uhi = max(uhi, mm[2 * i + 1]); }
+    if (include_zero) { ulo = min(ulo, f2ord(0.0f)); uhi = max(uhi, f2ord(0.0f)); }
     block_minmax(ulo, uhi);                  // ends in a barrier
   } else {
     __syncthreads();
@@ -242,6 +244,35 @@ inline size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
+namespace wmi {
+int route_unpermute_normalize(wm_ctx* ctx, const float* src, const wm_route* r, uint8_t* dst, size_t n, int n_planes, int do_norm,
+                              const unsigned* mm_ext, unsigned n_part_ext, int include_zero) {
+  WM_TRY(wmi::use_ctx(ctx));
+  if (n_planes < 0 || n_planes > 65535) return set_err(WM_ERR_BADARG, "n_planes must be in 0..65535");
+  if (!r) return set_err(WM_ERR_BADARG, "route is NULL");
+  if (r->n != n) return set_err(WM_ERR_BADARG, "the route was built for another plane size");
+  if (r->device != ctx->device) return set_err(WM_ERR_BADARG, "the route lives on another device");
+  if (n_planes == 0) return WM_OK;
+  if (!src || !dst) return set_err(WM_ERR_BADARG, "NULL argument");
+  WM_TRY(grow(ctx, &ctx->route_tmp, &ctx->route_tmp_bytes, (size_t)n_planes * n + (size_t)n_planes * MM_BLOCKS * 8 + 256, "route staging"));
+  uint8_t* tmp = (uint8_t*)ctx->route_tmp;
+  const unsigned* mm = mm_ext;
+  unsigned n_part = n_part_ext;
+  if (do_norm && !mm_ext) {
+    unsigned* mm_own = (unsigned*)((char*)ctx->route_tmp + a256((size_t)n_planes * n));
+    n_part = (unsigned)std::min<size_t>(MM_BLOCKS, (n / 4 + 256) / 256);
+    hipLaunchKernelGGL(k_minmax_planes, dim3(n_part, n_planes), dim3(256), 0, ctx->stream, src, n, mm_own);
+    mm = mm_own;
+  }
+  const size_t lds1 = (size_t)(2 * r->nb + 2) * 4 + r->S, lds2 = r->S;
+  hipLaunchKernelGGL(k_route_p1, dim3(r->nb, n_planes), dim3(ROUTE_NT), lds1, ctx->stream, src, n, r->log_s, r->nb, r->l1, r->bkt,
+                     r->lrs, r->cstart, mm, n_part, do_norm, include_zero, tmp);
+  hipLaunchKernelGGL(k_route_p2, dim3(r->nb, n_planes), dim3(ROUTE_NT), lds2, ctx->stream, tmp, n, r->log_s, r->l2, dst);
+  WM_HIP(hipGetLastError());
+  return WM_OK;
+}
+}  // namespace wmi
+
 extern "C" {
 
 int wm_route_create_dev(wm_ctx* ctx, const int* idx, size_t n, wm_route** route_out) {
@@ -318,25 +349,7 @@ int wm_route_destroy(wm_ctx* ctx, wm_route* r) {
 
 int wm_unpermute_normalize_u8_dev(wm_ctx* ctx, const float* src, const wm_route* r, uint8_t* dst, size_t n, int n_planes,
                                   int do_norm) {
-  WM_TRY(wmi::use_ctx(ctx));
-  if (n_planes < 0 || n_planes > 65535) return set_err(WM_ERR_BADARG, "n_planes must be in 0..65535");
-  if (!r) return set_err(WM_ERR_BADARG, "route is NULL");
-  if (r->n != n) return set_err(WM_ERR_BADARG, "the route was built for another plane size");
-  if (r->device != ctx->device) return set_err(WM_ERR_BADARG, "the route lives on another device");
-  if (n_planes == 0) return WM_OK;
-  if (!src || !dst) return set_err(WM_ERR_BADARG, "NULL argument");
-  WM_TRY(grow(ctx, &ctx->route_tmp, &ctx->route_tmp_bytes, (size_t)n_planes * n + (size_t)n_planes * MM_BLOCKS * 8 + 256, "route staging"));
-  uint8_t* tmp = (uint8_t*)ctx->route_tmp;
-  unsigned* mm = (unsigned*)((char*)ctx->route_tmp + a256((size_t)n_planes * n));
-  const unsigned n_part = (unsigned)std::min<size_t>(MM_BLOCKS, (n / 4 + 256) / 256);
-  if (do_norm)
-    hipLaunchKernelGGL(k_minmax_planes, dim3(n_part, n_planes), dim3(256), 0, ctx->stream, src, n, mm);
-  const size_t lds1 = (size_t)(2 * r->nb + 2) * 4 + r->S, lds2 = r->S;
-  hipLaunchKernelGGL(k_route_p1, dim3(r->nb, n_planes), dim3(ROUTE_NT), lds1, ctx->stream, src, n, r->log_s, r->nb, r->l1, r->bkt,
-                     r->lrs, r->cstart, mm, n_part, do_norm, tmp);
-  hipLaunchKernelGGL(k_route_p2, dim3(r->nb, n_planes), dim3(ROUTE_NT), lds2, ctx->stream, tmp, n, r->log_s, r->l2, dst);
-  WM_HIP(hipGetLastError());
-  return WM_OK;
+  return wmi::route_unpermute_normalize(ctx, src, r, dst, n, n_planes, do_norm, nullptr, 0, 0);
 }
 
 int wm_permute_u8_f32_routed_dev(wm_ctx* ctx, const uint8_t* src, const wm_route* r, float* dst, size_t n, int n_planes) {

@@ -570,15 +570,28 @@ __global__ __launch_bounds__(WAVE, 2) void k_svd_tiles(const float* __restrict__
 // ---------------------------------------------------------------------------
 // K2+K4  fused extract
 // ---------------------------------------------------------------------------
-template <bool ALIGNED, bool VECF, bool PX>
+// MM: the wave also leaves the {min, max} of its 4 096 outputs (order-preserving uint form) in mm[plane][tile group]: the
+// min-max pass of the normalise that follows the unscramble (single:221) costs nothing extra then.  Lanes past the last tile
+// of a partial wave recompute the last tile (every lane takes part in the reduction) and store nothing.
+template <bool ALIGNED, bool VECF, bool PX, bool MM>
 __global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
     const uint8_t* __restrict__ stego, const float* __restrict__ sigma_c,
     const float* __restrict__ Uw, const float* __restrict__ Vwt, float* __restrict__ out,
     const Geom g, const unsigned n_planes, const size_t uv_plane_stride, const float inv_alpha, const int K,
-    int* __restrict__ status) {
+    int* __restrict__ status, unsigned* __restrict__ mm) {
   int t, ty, tx;
   size_t plane;
-  if (!tile_coords_planefast(g, n_planes, t, ty, tx, plane)) return;
+  bool valid = true;
+  if (MM) {
+    const unsigned b = blockIdx.x, x = b % N_XCD, k = b / N_XCD;
+    const unsigned grp = x + N_XCD * (k / n_planes);
+    plane = k % n_planes;
+    if ((size_t)grp * WAVE >= (size_t)g.n_tiles) return;               // wave-uniform: a padding group
+    t = (int)(grp * WAVE + threadIdx.x);
+    valid = t < g.n_tiles;
+    t = valid ? t : g.n_tiles - 1;
+    ty = t / g.nbx; tx = t - ty * g.nbx;
+  } else if (!tile_coords_planefast(g, n_planes, t, ty, tx, plane)) return;
   wm::RawTile raw;
   float a[8][8], s[8], sc[8], keep[8];
   load_raw<ALIGNED>(stego + plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8,
@@ -594,8 +607,25 @@ __global__ __launch_bounds__(WAVE, 3) void k_extract_tiles(
   if (PX) wm::extract_tile_px(s, sc, inv_alpha, keep, uw, vwt, a);
   else wm::extract_tile(s, sc, inv_alpha, keep, uw, vwt, a);
   float* o = out + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
+  if (valid) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
+    for (int r = 0; r < 8; ++r) store_row8_f32<VECF>(o + (size_t)r * g.W, a[r]);
+  }
+  if (MM) {
+    float lo = a[0][0], hi = a[0][0];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { lo = fminf(lo, a[r][c]); hi = fmaxf(hi, a[r][c]); }
+    unsigned ulo = f2ord(lo), uhi = f2ord(hi);
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) { ulo = min(ulo, (unsigned)__shfl_down(ulo, o_, WAVE)); uhi = max(uhi, (unsigned)__shfl_down(uhi, o_, WAVE)); }
+    if (threadIdx.x == 0) {
+      const unsigned b = blockIdx.x, grp = b % N_XCD + N_XCD * ((b / N_XCD) / n_planes);
+      const size_t groups = ((size_t)g.n_tiles + WAVE - 1) / WAVE;
+      mm[2 * (plane * groups + grp)] = ulo; mm[2 * (plane * groups + grp) + 1] = uhi;
+    }
+  }
 }
 
 // out[i] = sum over planes z (ascending, deterministic) of in[z][i]: the frames of a clip carry the
@@ -843,6 +873,7 @@ int wm_destroy(wm_ctx* ctx) {
   if (ctx->ref_ws) (void)hipFree(ctx->ref_ws);
   if (ctx->ref_ws2) (void)hipFree(ctx->ref_ws2);
   if (ctx->route_tmp) (void)hipFree(ctx->route_tmp);
+  if (ctx->extract_f32) (void)hipFree(ctx->extract_f32);
   for (int i = 0; i < wm_ctx::MAX_PAIR_TABS; ++i) if (ctx->pair_tab[i]) (void)hipFree(ctx->pair_tab[i]);
   for (int i = 0; i < 2; ++i) if (ctx->dct_mat[i]) (void)hipFree(ctx->dct_mat[i]);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1016,7 +1047,7 @@ int wm_svd_tiles_f32_dev(wm_ctx* ctx, const float* planes, float* U, float* S, f
 // ---- K2+K4 -----------------------------------------------------------------
 static int extract_tiles_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
                              const float* Vwt, float* out, int n_planes, int H, int W, int row_stride,
-                             size_t plane_stride, size_t uv_plane_stride, float alpha, int K, bool px) {
+                             size_t plane_stride, size_t uv_plane_stride, float alpha, int K, bool px, unsigned* mm = nullptr) {
   WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
   if (!out) return set_err(WM_ERR_BADARG, "out is NULL");
   if (K < 0 || K > 8) return set_err(WM_ERR_BADARG, "K must be in 0..8");
@@ -1036,8 +1067,12 @@ static int extract_tiles_dev(wm_ctx* ctx, const uint8_t* stego, const float* sig
     return set_err(WM_ERR_BADARG, "more than 2^31 tile groups in one call");
   const dim3 grid = tile_grid_planefast(g, n_planes), block(WAVE);
 #define WM_LAUNCH_EXTRACT(A, V, P)                                                                    \
-  hipLaunchKernelGGL((k_extract_tiles<A, V, P>), grid, block, 0, ctx->stream, stego, sigma_c, Uw, Vwt, \
-                     out, g, (unsigned)n_planes, uv_plane_stride, inv_alpha, K, ctx->d_status)
+  do {                                                                                                \
+    if (mm) hipLaunchKernelGGL((k_extract_tiles<A, V, P, true>), grid, block, 0, ctx->stream, stego, sigma_c, Uw, Vwt, \
+                               out, g, (unsigned)n_planes, uv_plane_stride, inv_alpha, K, ctx->d_status, mm); \
+    else hipLaunchKernelGGL((k_extract_tiles<A, V, P, false>), grid, block, 0, ctx->stream, stego, sigma_c, Uw, Vwt, \
+                            out, g, (unsigned)n_planes, uv_plane_stride, inv_alpha, K, ctx->d_status, mm); \
+  } while (0)
   if (px) {
     if (al && vf) WM_LAUNCH_EXTRACT(true, true, true);
     else if (al) WM_LAUNCH_EXTRACT(true, false, true);
@@ -1066,6 +1101,30 @@ int wm_extract_tiles_px_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* s
                                size_t plane_stride, size_t uv_plane_stride, float alpha, int K) {
   return extract_tiles_dev(ctx, stego, sigma_c, Ux, Vxt, out, n_planes, H, W, row_stride, plane_stride,
                            uv_plane_stride, alpha, K, true);
+}
+
+// single:203-222 per plane in one call: sigma + rank-8 product (K2+K4) -> routed unscramble -> min-max normalise -> uint8.
+// The float estimate lives in a grow-only buffer of the context; the min / max come out of the extract kernel itself.
+int wm_extract_unscrambled_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw, const float* Vwt,
+                                  const wm_route* route, uint8_t* out, int n_planes, int H, int W, int row_stride,
+                                  size_t plane_stride, size_t uv_plane_stride, float alpha, int K, int px, int do_norm) {
+  WM_TRY(check_plane_args(ctx, stego, n_planes, H, W, row_stride, plane_stride));
+  if (!out || !route) return set_err(WM_ERR_BADARG, "out / route is NULL");
+  if (n_planes == 0 || H == 0 || W == 0) return WM_OK;
+  const size_t n = (size_t)H * W;
+  const Geom g = make_geom(H, W, row_stride, plane_stride);
+  const size_t groups = ((size_t)g.n_tiles + WAVE - 1) / WAVE;
+  const size_t f_bytes = ((size_t)n_planes * n * sizeof(float) + 255) & ~(size_t)255;
+  WM_TRY(grow(ctx, &ctx->extract_f32, &ctx->extract_f32_bytes, f_bytes + (size_t)n_planes * (groups + 1) * 2 * sizeof(unsigned) + 256,
+              "extract staging"));
+  float* w = (float*)ctx->extract_f32;
+  unsigned* mm = (unsigned*)((char*)ctx->extract_f32 + f_bytes);
+  const bool use_mm = do_norm && g.n_tiles > 0;
+  WM_TRY(extract_tiles_dev(ctx, stego, sigma_c, Uw, Vwt, w, n_planes, H, W, row_stride, plane_stride, uv_plane_stride, alpha, K,
+                           px != 0, use_mm ? mm : nullptr));
+  // pixels outside the tile grid (H % 8, W % 8) are zeros of the estimate: they take part in the min / max
+  return wmi::route_unpermute_normalize(ctx, w, route, out, n, n_planes, do_norm, use_mm ? mm : nullptr, (unsigned)groups,
+                                        ((H % 8) || (W % 8)) ? 1 : 0);
 }
 
 int wm_tile_factors_to_pixel_dev(wm_ctx* ctx, const float* Uw, const float* Vwt, float* Ux, float* Vxt,

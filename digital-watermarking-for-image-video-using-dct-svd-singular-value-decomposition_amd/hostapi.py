@@ -102,6 +102,7 @@ SIGNATURES = {
     "wm_route_destroy": [_vp, _vp],
     "wm_unpermute_normalize_u8_dev": [_vp, _vp, _vp, _vp, _sz, _i, _i],
     "wm_permute_u8_f32_routed_dev": [_vp, _vp, _vp, _vp, _sz, _i],
+    "wm_extract_unscrambled_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i, _i, _i],
     "wm_color_u8": [_vp, _i, _vp, _vp, _vp, _vp, _sz],
     "wm_psnr_u8": [_vp, _vp, _vp, _sz, C.POINTER(C.c_double)],
     "wm_ssim": [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_double)],
@@ -689,13 +690,21 @@ class Context:
         if sc.size != n * nby * nbx * 8 or Uw.shape[-4:] != (nby, nbx, 8, 8) or Vwt.shape != Uw.shape \
                 or (per_plane and Uw.shape[0] != n):
             raise ValueError("meta arrays do not match the planes")
-        bufs = [self.malloc(max(x, 16)) for x in (st.nbytes, sc.nbytes, Uw.nbytes, Vwt.nbytes, n * H * W * 4)]
+        route = self.route_dev(idx) if idx.size == H * W else None
+        bufs = [self.malloc(max(x, 16)) for x in (st.nbytes, sc.nbytes, Uw.nbytes, Vwt.nbytes,
+                                                   n * H * W if route is not None else n * H * W * 4)]
         d_st, d_sc, d_u, d_v, d_w = bufs
         try:
             self.h2d(d_st, st); self.h2d(d_sc, sc); self.h2d(d_u, Uw); self.h2d(d_v, Vwt)
-            self.extract_tiles_u8_dev(d_st, d_sc, d_u, d_v, d_w, n, H, W, W, H * W, nby * nbx if per_plane else 0,
-                                      float(alpha), int(K))
-            out = self._unpermute_normalize_dev(d_w, n, H, W, idx, normalize)
+            if route is not None:          # one call: extract kernel (with its min / max) -> routed unscramble -> uint8
+                self._call("wm_extract_unscrambled_u8_dev", _vp(d_st), _vp(d_sc), _vp(d_u), _vp(d_v), _vp(route), _vp(d_w),
+                           n, H, W, W, H * W, nby * nbx if per_plane else 0, float(alpha), int(K), 0, 1 if normalize else 0)
+                out = np.empty((n, H, W), np.uint8)
+                self.d2h(out, d_w)
+            else:
+                self.extract_tiles_u8_dev(d_st, d_sc, d_u, d_v, d_w, n, H, W, W, H * W, nby * nbx if per_plane else 0,
+                                          float(alpha), int(K))
+                out = self._unpermute_normalize_dev(d_w, n, H, W, idx, normalize)
             # the *_dev entry points only set the sticky status bit; without this a Jacobi that hit its sweep
             # bound would hand back a watermark silently and surface in some later, unrelated call (DESIGN 5:
             # non-convergence -> WM_ERR_NOCONV -> numpy.linalg.LinAlgError, like the host-pointer wrapper)

@@ -303,6 +303,15 @@ int wm_route_create_dev(wm_ctx* ctx, const int* idx, size_t n, wm_route** route_
 int wm_route_destroy(wm_ctx* ctx, wm_route* route);
 int wm_unpermute_normalize_u8_dev(wm_ctx* ctx, const float* src, const wm_route* route, uint8_t* dst, size_t n,
                                   int n_planes, int do_norm);
+/* The reference's extract per plane in ONE call (single:203-222 gray, :232-274 per colour plane): sigma of every stego tile,
+ * (S_cw - Sc) / max(alpha, 1e-8) with [K:] = 0, the rank-8 product with the watermark's factors (px != 0: pixel-domain
+ * factors from wm_tile_factors_to_pixel_dev, no per-tile IDCT; px == 0: Uw / Vwt as stored in the meta), the keyed
+ * unscramble through `route`, min-max normalise (do_norm) / clip / uint8.  The float estimate never leaves a buffer of
+ * the context and its min / max are taken by the extract kernel itself.  out [n_planes][H*W] uint8; bytes identical
+ * to wm_extract_tiles[_px]_u8_dev + wm_unpermute_normalize_u8_dev. */
+int wm_extract_unscrambled_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw, const float* Vwt,
+                                  const wm_route* route, uint8_t* out, int n_planes, int H, int W, int row_stride,
+                                  size_t plane_stride, size_t uv_plane_stride, float alpha, int K, int px, int do_norm);
 /* the scramble direction through the same route (single:66-72, 124-126): dst[p][i] = (float) src[p][idx[i]], uint8 planes
  * in, float32 out; values identical to wm_permute_u8_f32_dev */
 int wm_permute_u8_f32_routed_dev(wm_ctx* ctx, const uint8_t* src, const wm_route* route, float* dst, size_t n, int n_planes);

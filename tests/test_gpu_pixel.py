@@ -130,3 +130,48 @@ def test_routed_unscramble_normalise_is_bit_identical_to_the_index_pass(gpu_ctx)
     with pytest.raises(ValueError):
         c._call("wm_route_create_dev", vp(d_bad), bad.size, __import__("ctypes").byref(r))
     c.free(d_bad)
+
+
+def test_one_call_extract_equals_the_three_step_chain(gpu_ctx):
+    """wm_extract_unscrambled_u8_dev (single:203-222 per plane in one call; the extract kernel leaves its own min / max,
+    no separate min-max pass) against wm_extract_tiles[_px]_u8_dev + wm_unpermute_normalize_u8_dev: identical bytes -
+    full and ragged plane sizes (zeros outside the tile grid take part in the min / max), one plane and several,
+    DCT-domain and pixel-domain factors, with and without normalisation."""
+    import importlib
+    from conftest import PKG_NAME
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    hostapi = importlib.import_module(PKG_NAME + ".hostapi")
+    vp = hostapi._vp
+    rng = np.random.default_rng(29)
+    c = gpu_ctx
+    for (H, W, n_pl) in ((64, 96, 1), (128, 520, 3), (70, 101, 2), (1080, 1920, 2)):
+        n = H * W; nby, nbx = H // 8, W // 8; nt = nby * nbx
+        idx = hg.permutation_index(H, W, hg.derive_key(f"one{H}x{W}", bytes(8)))
+        route = c.route_dev(idx)
+        stego = rng.integers(0, 256, (n_pl, H, W), dtype=np.uint8)
+        wys = rng.integers(0, 256, (H, W)).astype(np.float32)
+        U, S, Vt = c.svd_tiles(wys)
+        sc = (c.sigma_tiles(stego) * rng.uniform(0.9, 1.0, (n_pl, nby, nbx, 8))).astype(np.float32)
+        d_st = c.malloc(stego.nbytes); c.h2d(d_st, stego)
+        d_sc = c.malloc(sc.nbytes); c.h2d(d_sc, sc)
+        d_u = c.malloc(U.nbytes); c.h2d(d_u, U); d_v = c.malloc(Vt.nbytes); c.h2d(d_v, Vt)
+        d_ux = c.malloc(U.nbytes); d_vx = c.malloc(Vt.nbytes)
+        c.tile_factors_to_pixel_dev(d_u, d_v, d_ux, d_vx, nt)
+        d_w = c.malloc(n_pl * n * 4); d_a = c.malloc(n_pl * n); d_b = c.malloc(n_pl * n)
+        for px in (0, 1):
+            fu, fv = (d_ux, d_vx) if px else (d_u, d_v)
+            for norm in (1, 0):
+                if px:
+                    c.extract_tiles_px_u8_dev(d_st, d_sc, fu, fv, d_w, n_pl, H, W, W, n, 0, 0.15, 8)
+                else:
+                    c.extract_tiles_u8_dev(d_st, d_sc, fu, fv, d_w, n_pl, H, W, W, n, 0, 0.15, 8)
+                c._call("wm_unpermute_normalize_u8_dev", vp(d_w), vp(route), vp(d_a), n, n_pl, norm)
+                a = np.empty((n_pl, n), np.uint8); c.d2h(a, d_a)
+                c._call("wm_extract_unscrambled_u8_dev", vp(d_st), vp(d_sc), vp(fu), vp(fv), vp(route), vp(d_b), n_pl, H, W, W, n, 0,
+                        0.15, 8, px, norm)
+                b = np.empty((n_pl, n), np.uint8); c.d2h(b, d_b)
+                assert np.array_equal(a, b), (H, W, n_pl, px, norm)
+                assert norm == 0 or (a.min(axis=1) == 0).all() and (a.max(axis=1) >= 254).all()
+        c.check_status()
+        for d in (d_st, d_sc, d_u, d_v, d_ux, d_vx, d_w, d_a, d_b):
+            c.free(d)
