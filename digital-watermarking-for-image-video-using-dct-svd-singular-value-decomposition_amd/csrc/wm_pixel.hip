@@ -246,7 +246,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
         rb[lane] = make_float4(a, b, fmaf(a, a, b * b), a * b);
         rb[SS_W + lane] = make_float4(c, d, fmaf(c, c, d * d), c * d);
       }
-      __syncthreads();                                     // one wave: orders this row's LDS writes before its reads
+#if defined(WM_SSIM_SYNC)
+      __syncthreads();
+#else
+      // one wave per workgroup: the LDS executes a wave's instructions in order, so this row's writes (all lanes) are
+      // done before its reads issue; only the COMPILER must be kept from hoisting a read of rb[lane + k] above the write
+      // of rb[lane] (different addresses per lane).  A scheduling barrier costs nothing; s_waitcnt + s_barrier did.
+      __builtin_amdgcn_wave_barrier();
+#endif
       float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
