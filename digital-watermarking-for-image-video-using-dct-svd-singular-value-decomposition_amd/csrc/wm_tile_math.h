@@ -786,6 +786,115 @@ WM_HD void embed_tile_rank1(const float (&x)[8][8], const float (&sw)[8], const 
   }
 }
 
+// ---- tiles with exactly ONE singular value out of the V-free form's reach (s_7 > 1e-5 s_1 >= s_8) --------------
+// On noise and camera content this is what the flagged tiles are (~50 per 4K frame): full rank but with s_8 so small
+// that  e_8 = w_8 / s_8^3  and  b_8^T X  cancel catastrophically - or rank 7 exactly.  They do not need the literal chain
+// (Jacobi with V, ~40 k instructions per wave): the seven good vectors of either side come from the fast path's own
+// B = X V (u_i = b_i / |b_i|, v_i = X^T b_i / s_i^2), and the eighth of either side is DETERMINED by them - the orthogonal
+// complement of seven vectors in R^8 is a line:  P = I - sum_i q_i q_i^T  is  q_8 q_8^T, so its column with the largest
+// diagonal entry (>= 1/8), orthogonalised once more and normalised, is q_8 up to sign (better than b_8 / |b_8|, whose
+// direction is only good to eps s_1 / s_8).  The joint sign of (u_8, v_8) is that of u_8^T X v_8 = +-s_8, evaluated in
+// FLOAT64: the vectors' float32 errors enter it only in second order (each is orthogonal to its side's other seven), so
+// the sign is right down to s_8 ~ 1e-12 s_1 - where the reference's float64 LAPACK stops resolving it too.  With
+// s_8 == 0 exactly the reference's pair is arbitrary and so is this one.   Yw = X + sum_i alpha sw_i u_i v_i^T, Sc = |b_i|.
+// bb[r][i] = component r of b_i (the layout of the fast kernel's packed a[r >> 1][i][r & 1]).
+WM_HD bool n2_one_small(const float (&n2)[8]) { return n2[6] > SIGMA_RATIO_MIN2 * n2[0]; }
+// r <- unit vector orthogonal to q_0 .. q_6, q_i[a] = Q(i, a) * scale[i]
+template <typename QF>
+WM_HD void complement_of_seven(const QF& Q, float (&r)[8]) {
+  float diag[8];                                   // of P = I - sum q_i q_i^T: only the diagonal and ONE column are formed
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    float acc = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc = ffma(-Q(i, a), Q(i, a), acc);
+    diag[a] = acc;
+  }
+  int best = 0;
+  float dbest = diag[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) { const bool gt = diag[k] > dbest; best = gt ? k : best; dbest = gt ? diag[k] : dbest; }
+  float qb[7];                                     // q_i[best]
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    float v = Q(i, 0);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = (best == k) ? Q(i, k) : v;
+    qb[i] = v;
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    float acc = (best == a) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc = ffma(-Q(i, a), qb[i], acc);
+    r[a] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {                    // once more against the seven: the column carries their rounding
+    float d = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) d = ffma(r[a], Q(i, a), d);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) r[a] = ffma(-d, Q(i, a), r[a]);
+  }
+  float n = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) n = ffma(r[a], r[a], n);
+  const float rn = frsq(n);
+#pragma unroll
+  for (int a = 0; a < 8; ++a) r[a] *= rn;
+}
+WM_HD void embed_tile_one_small(const float (&x)[8][8], const float (&bb)[8][8], const float (&sw)[8],
+                                const float (&alpha_k)[8], float (&sc)[8], float (&out)[8][8]) {
+  // three 8 x 8 arrays live at a time (x, B, V): u_i = b_i / |b_i| stays folded into the weights
+  float v[8][8];                                   // v[i][c]
+  float rs[8];                                     // 1 / |b_i|
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float n = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) n = ffma(bb[r][i], bb[r][i], n);
+    rs[i] = frsq(fmaxf(n, 1e-30f));
+    sc[i] = n * rs[i];
+  }
+  float u7[8];
+  complement_of_seven([&](const int i, const int a) { return bb[a][i] * rs[i]; }, u7);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const float r2 = rs[i] * rs[i];                // v_i = X^T b_i / s_i^2
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc = ffma(x[r][c], bb[r][i], acc);
+      v[i][c] = acc * r2;
+    }
+  }
+  complement_of_seven([&](const int i, const int a) { return v[i][a]; }, v[7]);
+  {
+    double d = 0.0;                                // sigma_8 >= 0: u_8^T X v_8 must not be negative (float64: see above)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      double t = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) t += (double)x[r][c] * (double)v[7][c];
+      d += (double)u7[r] * t;
+    }
+    const float sgn = (d < 0.0) ? -1.0f : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[7][c] *= sgn;
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = ffma(alpha_k[7] * sw[7] * u7[r], v[7][c], x[r][c]);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc = ffma(alpha_k[i] * sw[i] * rs[i] * bb[r][i], v[i][c], acc);
+      out[r][c] = acc;
+    }
+}
+
 WM_HD void add_completion(float (&a)[8][8], const float scale) {
 #pragma unroll
   for (int r = 0; r < 8; ++r)

@@ -55,6 +55,7 @@ namespace {
 constexpr int N_SUMS = 5;          // detect: sum a, b, ab, aa, bb
 constexpr unsigned FB_SUB = 64;    // embed: sub-lists per kind of flagged tile (one per lane of the fallback kernel's scan)
 constexpr unsigned FB_PAD = 32;    // ints between two sub-list counters: one 128-byte line each
+constexpr unsigned FB_KINDS = 4;   // 0 literal chain, 1 constant, 2 rank 1, 3 one small singular value (B kept in fb_b)
 
 // The iteration every tile kernel spends its time in (B = X V by one-sided Jacobi) is a generated,
 // hand-scheduled gfx950 stream with pinned registers (tools/gen_jacobi_asm.py); -DWM_NO_ASM_JACOBI
@@ -277,7 +278,7 @@ inline dim3 tile_grid_planefast(const Geom& g, int n_planes) {
 // K1  fused embed   (a1 a2 a3 a4 a5 a6 a7; sigma_c side output)
 // ---------------------------------------------------------------------------
 // Fast path: packed, V-free, pixel-domain (wm_tile_math.h identities (1),(2)).
-// Flat / rank-deficient tiles append their id to `fb_list` (count = status[1])
+// Flat / rank-deficient tiles append their id to one of the flagged-tile lists in `fb_list` (see append_kind)
 // and are redone by k_embed_fallback.
 #ifndef WM_EMBED_WAVES
 #define WM_EMBED_WAVES 3
@@ -288,6 +289,7 @@ __device__ __forceinline__ void embed_group(
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom& g, const size_t sw_plane_stride, const float alpha, const int K,
     int* __restrict__ status, uint32_t* __restrict__ fb_list, int* __restrict__ fb_cnt, const uint32_t fb_cap,
+    float* __restrict__ fb_b, const uint32_t fb_cap3,
     const int t, const int ty, const int tx, const size_t plane) {
   const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
 
@@ -360,7 +362,39 @@ __device__ __forceinline__ void embed_group(
     // fallback kernel must still read the original pixels; it also writes their Sc
     if (!deficient) store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
   }
-  append_kind(deficient && !cst && r1 == 0, 0);
+  // one singular value out of reach (s_7 > 1e-5 s_1 >= s_8): kind 3 - the fallback kernel completes the tile from THIS
+  // B (wm::embed_tile_one_small), no Jacobi with V.  B goes to fb_b (256 bytes per tile; kind 3's sub-lists hold fb_cap3
+  // entries each, what does not fit takes the literal chain like everything of lower rank).
+  bool one_small = deficient && !cst && r1 == 0 && wm::n2_one_small(n2);
+#if defined(WM_EXP_NO_ONE_SMALL)    // A/B only: everything flagged that is not constant / rank 1 takes the literal chain (round 2 behaviour)
+  one_small = false;
+#endif
+  {
+    const unsigned long long dmask = __builtin_amdgcn_ballot_w64(one_small);
+    if (dmask != 0ull) {
+      const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const unsigned leader = (unsigned)__builtin_ctzll(dmask);
+      const unsigned l = 3u * FB_SUB + fb_sub;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(fb_cnt + (size_t)l * FB_PAD, (int)__builtin_popcountll(dmask));
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (one_small) {
+        const unsigned slot = (unsigned)base + (unsigned)__builtin_popcountll(dmask & ((1ull << lane) - 1ull));
+        if (slot < fb_cap3) {
+          const size_t pos = (size_t)fb_sub * fb_cap3 + slot;
+          fb_list[(size_t)3 * FB_SUB * fb_cap + pos] = (uint32_t)(plane * g.n_tiles + t);
+          wm::v2f* dstb = reinterpret_cast<wm::v2f*>(fb_b + pos * 64);
+#pragma unroll
+          for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dstb[rp * 8 + c] = a[rp][c];
+        } else {
+          one_small = false;                        // sub-list full: the literal chain
+        }
+      }
+    }
+  }
+  append_kind(deficient && !cst && r1 == 0 && !one_small, 0);
   append_kind(cst, 1);
   append_kind(r1 != 0, 2);
   if (sweeps < 0) atomicOr(status, 1);
@@ -386,13 +420,13 @@ __global__ __launch_bounds__(WAVE, WM_EMBED_WAVES) void k_embed_tiles(
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const unsigned n_groups, const size_t sw_plane_stride,
     const float alpha, const int K, int* __restrict__ status, uint32_t* __restrict__ fb_list, int* __restrict__ fb_cnt,
-    const uint32_t fb_cap) {
+    const uint32_t fb_cap, float* __restrict__ fb_b, const uint32_t fb_cap3) {
   const unsigned w = blockIdx.x;
   const unsigned plane = w / n_groups, grp = w - plane * n_groups;
   const int t = (int)(grp * WAVE + threadIdx.x);
   if (t >= g.n_tiles) return;
   const int ty = t / g.nbx, tx = t - ty * g.nbx;
-  embed_group<ALIGNED, YW>(host, sigma_w, stego, sigma_c, yw, g, sw_plane_stride, alpha, K, status, fb_list, fb_cnt, fb_cap,
+  embed_group<ALIGNED, YW>(host, sigma_w, stego, sigma_c, yw, g, sw_plane_stride, alpha, K, status, fb_list, fb_cnt, fb_cap, fb_b, fb_cap3,
                            t, ty, tx, (size_t)plane);
 }
 
@@ -407,7 +441,8 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
     const uint8_t* host, const float* __restrict__ sigma_w,
     uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
     const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
-    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const int* __restrict__ fb_cnt, const uint32_t fb_cap) {
+    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const int* __restrict__ fb_cnt, const uint32_t fb_cap,
+    const float* __restrict__ fb_b, const uint32_t fb_cap3) {
   float alpha_k[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
@@ -424,22 +459,27 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
   // item `it` of kind k: the sub-lists' counts are scanned in the wave (lane l holds sub-list l), the owning sub-list is
   // found by a 6-step search over the lanes' prefix sums
   static_assert(FB_SUB == WAVE, "one sub-list per lane");
-  int pre[3], total[3];
+  int pre[FB_KINDS], total[FB_KINDS];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int c = fb_cnt[(size_t)(k * FB_SUB + threadIdx.x) * FB_PAD];
+  for (int k = 0; k < (int)FB_KINDS; ++k) {
+    int c = fb_cnt[(size_t)(k * FB_SUB + threadIdx.x) * FB_PAD];
+    if (k == 3) c = min(c, (int)fb_cap3);           // what did not fit went to kind 0
     int incl = c;
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) { const int v = __shfl_up(incl, o, WAVE); if ((int)threadIdx.x >= o) incl += v; }
     pre[k] = incl - c;
     total[k] = __shfl(incl, WAVE - 1, WAVE);
   }
-  auto item = [&](const int k, const int it) -> uint32_t {      // `it` < total[k]
+  auto locate = [&](const int k, const int it, int& sub, int& j) {      // `it` < total[k]
     int s_ = 0;
 #pragma unroll
     for (int o = WAVE / 2; o > 0; o >>= 1) { const int p_ = __shfl(pre[k], s_ + o, WAVE); if (p_ <= it) s_ += o; }
-    const int p0 = __shfl(pre[k], s_, WAVE);
-    return fb_list[(size_t)(k * FB_SUB + s_) * fb_cap + (it - p0)];
+    sub = s_; j = it - __shfl(pre[k], s_, WAVE);
+  };
+  auto item = [&](const int k, const int it) -> uint32_t {
+    int sub, j;
+    locate(k, it, sub, j);
+    return fb_list[(size_t)(k * FB_SUB + sub) * fb_cap + j];
   };
   const int count = total[0], n_const = total[1], n_rank1 = total[2];
   for (int it0 = blockIdx.x * WAVE; it0 < count; it0 += gridDim.x * WAVE) {      // wave-uniform bounds: the shuffles need every lane
@@ -487,6 +527,85 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
     load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
     load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
     wm::embed_tile_rank1(a, sw, alpha_k, sc, a);
+    finish(plane, t, off, sc, a);
+  }
+}
+
+// Kind 3 of the flagged-tile lists (one singular value out of reach: wm::embed_tile_one_small) in a kernel of its own, one
+// wave per SIMD: three 8 x 8 arrays and a float64 bilinear form need 314-362 registers; inside k_embed_fallback they pushed
+// the literal chain's 202-228 VGPRs into scratch.  Same list walk.
+// (k_embed_fallback: the tiles listed by the fast kernel, one per lane, a fixed grid striding each list - the counts are only known on
+// the device): first the literal chain with orthonormal completion (wm::embed_tile_completed) for the front list,
+// then the closed form of the constant tiles (wm::embed_tile_constant) for the back list.
+#ifndef WM_FALLBACK_WAVES
+#define WM_FALLBACK_WAVES 2
+#endif
+template <bool ALIGNED, bool YW>
+__global__ __launch_bounds__(WAVE, 1) void k_embed_one_small(
+    const uint8_t* host, const float* __restrict__ sigma_w,
+    uint8_t* stego, float* __restrict__ sigma_c, float* __restrict__ yw,
+    const Geom g, const size_t sw_plane_stride, const float alpha, const int K,
+    int* __restrict__ status, const uint32_t* __restrict__ fb_list, const int* __restrict__ fb_cnt, const uint32_t fb_cap,
+    const float* __restrict__ fb_b, const uint32_t fb_cap3) {
+  float alpha_k[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) alpha_k[i] = (i < K) ? alpha : 0.0f;
+  auto finish = [&](const size_t plane, const int t, const size_t off, const float (&sc)[8], float (&a)[8][8]) {
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
+    store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
+    store_tile_u8<ALIGNED>(stego + off, g.row_stride, a);
+    if (YW) {
+      float* o = yw + plane * g.HW + (size_t)ty * 8 * g.W + (size_t)tx * 8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) store_row8_f32<false>(o + (size_t)r * g.W, a[r]);
+    }
+  };
+  // item `it` of kind k: the sub-lists' counts are scanned in the wave (lane l holds sub-list l), the owning sub-list is
+  // found by a 6-step search over the lanes' prefix sums
+  static_assert(FB_SUB == WAVE, "one sub-list per lane");
+  int pre[FB_KINDS], total[FB_KINDS];
+#pragma unroll
+  for (int k = 0; k < (int)FB_KINDS; ++k) {
+    int c = fb_cnt[(size_t)(k * FB_SUB + threadIdx.x) * FB_PAD];
+    if (k == 3) c = min(c, (int)fb_cap3);           // what did not fit went to kind 0
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) { const int v = __shfl_up(incl, o, WAVE); if ((int)threadIdx.x >= o) incl += v; }
+    pre[k] = incl - c;
+    total[k] = __shfl(incl, WAVE - 1, WAVE);
+  }
+  auto locate = [&](const int k, const int it, int& sub, int& j) {      // `it` < total[k]
+    int s_ = 0;
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) { const int p_ = __shfl(pre[k], s_ + o, WAVE); if (p_ <= it) s_ += o; }
+    sub = s_; j = it - __shfl(pre[k], s_, WAVE);
+  };
+  auto item = [&](const int k, const int it) -> uint32_t {
+    int sub, j;
+    locate(k, it, sub, j);
+    return fb_list[(size_t)(k * FB_SUB + sub) * fb_cap + j];
+  };
+  const int n_small = total[3];
+  for (int it0 = blockIdx.x * WAVE; it0 < n_small; it0 += gridDim.x * WAVE) {
+    const int it = it0 + threadIdx.x;
+    int sub, j;
+    locate(3, min(it, n_small - 1), sub, j);
+    if (it >= n_small) continue;
+    const size_t pos = (size_t)sub * fb_cap3 + j;
+    const uint32_t id = fb_list[(size_t)3 * FB_SUB * fb_cap + pos];
+    const size_t plane = id / (uint32_t)g.n_tiles;
+    const int t = (int)(id % (uint32_t)g.n_tiles);
+    const int ty = t / g.nbx, tx = t - ty * g.nbx;
+    const size_t off = plane * g.plane_stride + (size_t)ty * 8 * g.row_stride + (size_t)tx * 8;
+    float a[8][8], bb[8][8], sw[8], sc[8];
+    load_tile_u8<ALIGNED>(host + off, g.row_stride, a);
+    const wm::v2f* srcb = reinterpret_cast<const wm::v2f*>(fb_b + pos * 64);
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const wm::v2f v = srcb[rp * 8 + c]; bb[2 * rp][c] = v[0]; bb[2 * rp + 1][c] = v[1]; }
+    load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
+    wm::embed_tile_one_small(a, bb, sw, alpha_k, sc, a);
     finish(plane, t, off, sc, a);
   }
 }
@@ -977,10 +1096,16 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
     // then the padded counters
     const size_t cap = (n_work_sz + FB_SUB - 1) / FB_SUB * WAVE;
     if (cap > 0x7fffffffull) return set_err(WM_ERR_BADARG, "more than 2^31 tiles in one call");
-    const size_t list_bytes = (size_t)3 * FB_SUB * cap * sizeof(uint32_t), cnt_bytes = (size_t)3 * FB_SUB * FB_PAD * sizeof(int);
-    WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, list_bytes + cnt_bytes, "fallback lists"));
+    // kind 3 keeps its tiles' B (256 bytes each): its sub-lists hold cap / 16 entries (>= 64), the rest takes the literal chain
+    const size_t cap3 = std::max<size_t>(WAVE, cap / 16);
+    const size_t list_bytes = ((size_t)3 * FB_SUB * cap + (size_t)FB_SUB * cap3) * sizeof(uint32_t);
+    const size_t cnt_bytes = (size_t)FB_KINDS * FB_SUB * FB_PAD * sizeof(int);
+    const size_t b_off = (list_bytes + cnt_bytes + 255) & ~(size_t)255;
+    WM_TRY(grow(ctx, &ctx->fb_list, &ctx->fb_bytes, b_off + (size_t)FB_SUB * cap3 * 64 * sizeof(float), "fallback lists"));
     uint32_t* fb = (uint32_t*)ctx->fb_list;
     int* fb_cnt = (int*)((char*)ctx->fb_list + list_bytes);
+    float* fb_b = (float*)((char*)ctx->fb_list + b_off);
+    const uint32_t fb_cap3 = (uint32_t)cap3;
     WM_HIP(hipMemsetAsync(fb_cnt, 0, cnt_bytes, ctx->stream));
     const uint32_t fb_cap = (uint32_t)cap;
     const dim3 fgrid((unsigned)(n_waves < 2048 ? n_waves : 2048));
@@ -988,10 +1113,13 @@ int wm_embed_tiles_u8_dev(wm_ctx* ctx, const uint8_t* host, const float* sigma_w
   do {                                                                                             \
     hipLaunchKernelGGL((k_embed_tiles<A, Y>), grid, block, 0, ctx->stream, host, sigma_w, stego,   \
                        sigma_c, yw, g, n_groups, sigma_w_plane_stride, alpha, K,                   \
-                       ctx->d_status, fb, fb_cnt, fb_cap);                                          \
+                       ctx->d_status, fb, fb_cnt, fb_cap, fb_b, fb_cap3);                           \
     hipLaunchKernelGGL((k_embed_fallback<A, Y>), fgrid, block, 0, ctx->stream, host, sigma_w,      \
                        stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb,   \
-                       fb_cnt, fb_cap);                                                            \
+                       fb_cnt, fb_cap, fb_b, fb_cap3);                                             \
+    hipLaunchKernelGGL((k_embed_one_small<A, Y>), fgrid, block, 0, ctx->stream, host, sigma_w,     \
+                       stego, sigma_c, yw, g, sigma_w_plane_stride, alpha, K, ctx->d_status, fb,   \
+                       fb_cnt, fb_cap, fb_b, fb_cap3);                                             \
   } while (0)
     if (al && yw) WM_LAUNCH_EMBED(true, true);
     else if (al) WM_LAUNCH_EMBED(true, false);

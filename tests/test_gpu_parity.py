@@ -238,6 +238,57 @@ def test_rank1_tiles_take_the_closed_form(gpu_ctx):
     assert np.array_equal(buf, stego) and np.array_equal(sc_ip.reshape(sc.shape), sc)
 
 
+def test_one_small_singular_value_tiles_on_gpu(gpu_ctx):
+    """Kind 3 of the flagged-tile lists (k_embed_one_small): tiles whose eighth singular value is below 1e-5 sigma_1 - what
+    noise frames contain, 4 in 10 000 - are completed from the fast kernel's own B, both eighth vectors as orthogonal
+    complements, their joint sign from a float64 bilinear form.  Near-singular FULL-rank tiles have unique singular
+    vectors: 1 LSB against float64 LAPACK (the literal chain they used to take was off by 3 LSB on the ones below
+    float32 resolution: tools/one_small_check.py); rank-7 tiles satisfy the reference's invariant; a plane made of rank-7
+    tiles only overflows the kind's sub-lists into the literal chain and still satisfies it."""
+    from test_host_harness import _one_small_tiles
+    near, r7 = _one_small_tiles(n_want=40, seed=9)
+    rng = np.random.default_rng(3)
+    H, W = 64, 1024
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    nby, nbx = H // 8, W // 8
+    where = []
+    for k, t in enumerate(near + r7):                              # scattered over the plane: mixed waves
+        ty, tx = (7 * k) % nby, (13 * k + 5) % nbx
+        img[ty * 8: ty * 8 + 8, tx * 8: tx * 8 + 8] = t
+        where.append((ty, tx))
+    assert len(set(where)) == len(where)
+    sw = np.sort(rng.uniform(1, 1500, (nby, nbx, 8)).astype(np.float32), axis=-1)[..., ::-1].copy()
+    stego, sc, yw = gpu_ctx.embed_tiles(img, sw, 0.15, want_yw=True)
+    T = lambda x: x.reshape(nby, 8, nbx, 8).transpose(0, 2, 1, 3)
+    X = T(img).astype(np.float64)
+    U, S, Vt = np.linalg.svd(X)
+    ref = (U * (S + 0.15 * sw)[..., None, :]) @ Vt
+    full = S[..., 7] > 1e-9 * S[..., 0]                            # everything but the exactly rank-7 tiles: unique vectors
+    q = np.abs(np.clip(T(yw), 0, 255).astype(np.uint8).astype(int) - np.clip(ref, 0, 255).astype(np.uint8).astype(int))
+    assert q[full].max() <= 1 and np.mean(q[full] != 0) < 1e-3
+    near_idx = tuple(np.array(where[:len(near)]).T)
+    assert (S[near_idx][:, 7] < 1e-5 * S[near_idx][:, 0]).all()
+    assert np.abs(T(yw)[near_idx] - ref[near_idx]).max() < 0.05
+    got = np.linalg.svd(T(yw).astype(np.float64), compute_uv=False)
+    want = np.sort(sc.astype(np.float64) + 0.15 * sw, axis=-1)[..., ::-1]
+    assert np.max(np.abs(got - want) / want[..., :1]) < 1e-4
+    assert np.max(np.abs(sc - S) / S[..., :1]) < 2e-6
+    assert np.array_equal(stego, np.clip(yw, 0, 255).astype(np.uint8))
+    # a plane of rank-7 tiles only (two equal rows in every tile): 256 waves on 64 sub-lists of 64 entries - most of the tiles
+    # overflow into the literal chain
+    big = rng.integers(0, 256, (1024, 1024), dtype=np.uint8)
+    big[5::8] = big[2::8]
+    swb = np.sort(rng.uniform(1, 1500, (128, 128, 8)).astype(np.float32), axis=-1)[..., ::-1].copy()
+    st2, sc2, yw2 = gpu_ctx.embed_tiles(big, swb, 0.15, want_yw=True)
+    T2 = yw2.reshape(128, 8, 128, 8).transpose(0, 2, 1, 3).astype(np.float64)
+    got = np.linalg.svd(T2, compute_uv=False)
+    want = np.sort(sc2.astype(np.float64) + 0.15 * swb, axis=-1)[..., ::-1]
+    assert np.isfinite(yw2).all() and np.max(np.abs(got - want) / want[..., :1]) < 1e-4
+    s_true = np.linalg.svd(big.reshape(128, 8, 128, 8).transpose(0, 2, 1, 3).astype(np.float64), compute_uv=False)
+    assert np.max((np.abs(sc2 - s_true) - 4 * 2.0 ** -14) / s_true[..., :1]) < 1e-5
+    gpu_ctx.check_status()
+
+
 def test_unaligned_and_strided_planes(gpu_ctx, hostapi):
     """Byte-wise kernel variants: row stride / base address not multiples of 8,
     planes embedded in a larger buffer (row_stride > W, plane_stride > H*row_stride)."""

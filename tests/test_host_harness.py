@@ -312,3 +312,58 @@ def test_rank1_tiles_take_the_closed_form_in_the_plane_path(hh):
     assert not sc.reshape(H // 8, W // 8, 8)[r1][:, 1:].any()      # closed form: exact zeros, not the pattern's delta-sized values
     rank2 = np.zeros_like(r1); rank2[12:, 4:8] = True              # _degenerate_image's rank-2 block: the literal chain, delta-sized values
     assert (sc.reshape(H // 8, W // 8, 8)[rank2][:, 2:] > 0).all()
+
+
+def _one_small_tiles(n_want=24, seed=5):
+    """uint8 tiles with exactly one singular value below 1e-5 sigma_1: random tiles that happen to be that close to
+    singular (what noise frames contain, ~4 in 10 000) and exactly rank-7 ones (two equal rows, a zero column, a column
+    that is the sum of two others)."""
+    rng = np.random.default_rng(seed)
+    found = []
+    while len(found) < n_want:
+        t = rng.integers(0, 256, (200000, 8, 8)).astype(np.float64)
+        s = np.linalg.svd(t, compute_uv=False)
+        sel = (s[:, 7] < 1e-5 * s[:, 0]) & (s[:, 6] > 1e-3 * s[:, 0])
+        found += [x.astype(np.uint8) for x in t[sel]]
+    near = found[:n_want]
+    r7 = []
+    for k in range(8):
+        a = rng.integers(0, 256, (8, 8)).astype(np.uint8)
+        if k % 3 == 0: a[5] = a[2]
+        elif k % 3 == 1: a[:, 3] = 0
+        else: a[:, 6] = (a[:, 0].astype(int) // 2 + a[:, 1].astype(int) // 2).astype(np.uint8); a[:, 0] = (a[:, 0] // 2) * 2; a[:, 1] = (a[:, 1] // 2) * 2; a[:, 6] = a[:, 0] // 2 + a[:, 1] // 2
+        r7.append(a)
+    return near, r7
+
+
+def test_one_small_singular_value_is_completed_without_v(hh):
+    """embed_tile_one_small (csrc/wm_tile_math.h): tiles whose eighth singular value is out of the V-free form's reach
+    (or exactly 0) are finished from the fast path's own B = X V - seven right vectors as usual, the eighth as the
+    orthogonal complement of the seven - instead of the Jacobi with V.  Near-singular FULL-rank tiles have unique
+    singular vectors, so they must match the float64 oracle to 1 LSB; rank-7 tiles (sign of the null pair arbitrary)
+    must satisfy the reference's invariant svd(Yw) = Sc + alpha Sw."""
+    near, r7 = _one_small_tiles()
+    tiles = near + r7
+    H, W = 8, 8 * len(tiles)
+    img = np.concatenate(tiles, axis=1)
+    rng = np.random.default_rng(2)
+    sw = np.sort(rng.uniform(1, 1500, (len(tiles), 8)).astype(np.float32), axis=-1)[..., ::-1].copy()
+    stego = np.empty((H, W), np.uint8); sc = np.empty((len(tiles), 8), np.float32); yw = np.empty((H, W), np.float32)
+    ms = C.c_int(0); nf = C.c_int(0)
+    hh.hh_embed_tiles_u8_pk(vp(img), vp(sw), vp(stego), vp(sc), vp(yw), H, W, W, C.c_float(0.15), 8, C.byref(ms), C.byref(nf))
+    assert nf.value == len(tiles)                                   # every one of them is flagged by the fast path
+    T = yw.reshape(8, len(tiles), 8).transpose(1, 0, 2).astype(np.float64)
+    X = np.stack(tiles).astype(np.float64)
+    sx = np.linalg.svd(X, compute_uv=False)
+    assert np.max(np.abs(sc - sx) / sx[:, :1]) < 2e-6
+    want = np.sort(sc.astype(np.float64) + 0.15 * sw, axis=1)[:, ::-1]
+    got = np.linalg.svd(T, compute_uv=False)
+    assert np.max(np.abs(got - want) / want[:, :1]) < 2e-5
+    assert np.array_equal(stego, np.clip(yw, 0, 255).astype(np.uint8))
+    # the near-singular full-rank ones against float64 LAPACK: U diag(S + alpha Sw) V^T
+    U, S, Vt = np.linalg.svd(X[:len(near)])
+    ref = (U * (S + 0.15 * sw[:len(near)])[:, None, :]) @ Vt
+    d = np.abs(T[:len(near)] - ref)
+    assert d.max() < 0.05, d.max()                                  # grey levels; the literal chain manages ~1e-2 here
+    q = np.abs(np.clip(ref, 0, 255).astype(np.uint8).astype(int) - np.clip(T[:len(near)], 0, 255).astype(np.uint8).astype(int))
+    assert q.max() <= 1

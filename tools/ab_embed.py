@@ -76,7 +76,7 @@ def main():
         c = d["ctx"]
         st = np.empty((F, H, W), np.uint8); c.d2h(st, d["stego"])
         sc = np.empty((F, nt, 8), np.float32); c.d2h(sc, d["sc"])
-        wm = np.empty((2, H, W), np.float32); c.d2h(wm, d["out"])
+        wm = np.empty((min(2, F), H, W), np.float32); c.d2h(wm, d["out"])
         if ref is None:
             ref = (st, sc, wm)
         dd = np.abs(st.astype(np.int16) - ref[0].astype(np.int16))
