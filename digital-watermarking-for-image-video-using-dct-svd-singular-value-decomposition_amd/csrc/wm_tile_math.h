@@ -895,6 +895,90 @@ WM_HD void embed_tile_one_small(const float (&x)[8][8], const float (&bb)[8][8],
     }
 }
 
+// ---- any rank from 2 to 6: the same construction with more than one missing pair ------------------------------
+// Ranks i with s_i > 1e-5 s_1 take u_i, v_i from B as above; every other rank gets a pair (u_j, v_j) from the orthogonal
+// complements of what is there so far, one vector at a time (largest diagonal entry of the current projector, orthogonalised
+// once more, normalised).  More than one missing direction per side: the reference's completion is arbitrary (LAPACK's
+// choice of a basis of the null spaces) and so is this one; what holds whatever the choice - svd(Yw) = Sc + alpha Sw,
+// Sc = the tile's singular values, the injected energy - is what the tests check.  u[i][r], v[i][c] hold zero vectors for
+// the ranks not filled yet, so every sum runs over all eight slots.
+WM_HD void complete_next(const float (&q)[8][8], float (&r)[8]) {
+  float diag[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    float acc = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = ffma(-q[i][a], q[i][a], acc);
+    diag[a] = acc;
+  }
+  int best = 0;
+  float dbest = diag[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) { const bool gt = diag[k] > dbest; best = gt ? k : best; dbest = gt ? diag[k] : dbest; }
+#pragma unroll
+  for (int a = 0; a < 8; ++a) r[a] = (best == a) ? 1.0f : 0.0f;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float d = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) d = ffma(r[a], q[i][a], d);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) r[a] = ffma(-d, q[i][a], r[a]);
+    }
+  float n = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) n = ffma(r[a], r[a], n);
+  const float rn = frsq(n);
+#pragma unroll
+  for (int a = 0; a < 8; ++a) r[a] *= rn;
+}
+WM_HD void embed_tile_from_b(const float (&x)[8][8], const float (&bb)[8][8], const float (&sw)[8],
+                             const float (&alpha_k)[8], float (&sc)[8], float (&out)[8][8]) {
+  float u[8][8], v[8][8];
+  bool good[8];
+  float n0 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float n = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) n = ffma(bb[r][i], bb[r][i], n);
+    if (i == 0) n0 = n;
+    const float rs = frsq(fmaxf(n, 1e-30f));
+    sc[i] = n * rs;
+    good[i] = n > SIGMA_RATIO_MIN2 * n0 && n > 0.0f;
+    const float g = good[i] ? rs : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[i][r] = bb[r][i] * g;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc = ffma(x[r][c], u[i][r], acc);
+      v[i][c] = acc * g;                           // X^T u_i / s_i  (0 for the ranks to be completed)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (!good[j]) {
+      float ru[8], rv[8];
+      complete_next(u, ru);
+      complete_next(v, rv);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) { u[j][a] = ru[a]; v[j][a] = rv[a]; }
+    }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = x[r][c];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = ffma(alpha_k[i] * sw[i] * u[i][r], v[i][c], acc);
+      out[r][c] = acc;
+    }
+}
+
 WM_HD void add_completion(float (&a)[8][8], const float scale) {
 #pragma unroll
   for (int r = 0; r < 8; ++r)

@@ -362,10 +362,11 @@ __device__ __forceinline__ void embed_group(
     // fallback kernel must still read the original pixels; it also writes their Sc
     if (!deficient) store_row8_f32<true>(sigma_c + (plane * g.n_tiles + t) * 8, sc);
   }
-  // one singular value out of reach (s_7 > 1e-5 s_1 >= s_8): kind 3 - the fallback kernel completes the tile from THIS
-  // B (wm::embed_tile_one_small), no Jacobi with V.  B goes to fb_b (256 bytes per tile; kind 3's sub-lists hold fb_cap3
-  // entries each, what does not fit takes the literal chain like everything of lower rank).
-  bool one_small = deficient && !cst && r1 == 0 && wm::n2_one_small(n2);
+  // Every other flagged tile - one singular value out of reach (noise / camera content) or rank 2 .. 6 (structured content) -
+  // is kind 3: k_embed_one_small completes it from THIS B (wm::embed_tile_one_small / embed_tile_from_b), no Jacobi with
+  // V.  B goes to fb_b (256 bytes per tile; kind 3's sub-lists hold fb_cap3 entries each, what does not fit takes the
+  // literal chain).
+  bool one_small = deficient && !cst && r1 == 0;
 #if defined(WM_EXP_NO_ONE_SMALL)    // A/B only: everything flagged that is not constant / rank 1 takes the literal chain (round 2 behaviour)
   one_small = false;
 #endif
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
   }
 }
 
-// Kind 3 of the flagged-tile lists (one singular value out of reach: wm::embed_tile_one_small) in a kernel of its own, one
+// Kind 3 of the flagged-tile lists (completed from the fast kernel's B: wm::embed_tile_one_small / embed_tile_from_b) in a kernel of its own, one
 // wave per SIMD: three 8 x 8 arrays and a float64 bilinear form need 314-362 registers; inside k_embed_fallback they pushed
 // the literal chain's 202-228 VGPRs into scratch.  Same list walk.
 // (k_embed_fallback: the tiles listed by the fast kernel, one per lane, a fixed grid striding each list - the counts are only known on
@@ -605,7 +606,13 @@ __global__ __launch_bounds__(WAVE, 1) void k_embed_one_small(
 #pragma unroll
       for (int c = 0; c < 8; ++c) { const wm::v2f v = srcb[rp * 8 + c]; bb[2 * rp][c] = v[0]; bb[2 * rp + 1][c] = v[1]; }
     load_row8_f32<true>(sigma_w + plane * sw_plane_stride + (size_t)t * 8, sw);
-    wm::embed_tile_one_small(a, bb, sw, alpha_k, sc, a);
+    float n6 = 0.0f, n0 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { n6 = __builtin_fmaf(bb[r][6], bb[r][6], n6); n0 = __builtin_fmaf(bb[r][0], bb[r][0], n0); }
+    // one missing pair: its joint sign is defined (float64 inside); more than one: any orthonormal completion
+    const bool one = n6 > wm::SIGMA_RATIO_MIN2 * n0;
+    if (wm::wave_any(one)) { if (one) wm::embed_tile_one_small(a, bb, sw, alpha_k, sc, a); }
+    if (wm::wave_any(!one)) { if (!one) wm::embed_tile_from_b(a, bb, sw, alpha_k, sc, a); }
     finish(plane, t, off, sc, a);
   }
 }

@@ -147,12 +147,12 @@ int hh_embed_tiles_u8_pk(const uint8_t* host, const float* sigma_w, uint8_t* ste
         raw_to_f32(raw, y);
         if (raw_is_constant(raw)) { embed_tile_constant(y[0][0], sw, alpha_k, sc, y); s = 1; }   // like k_embed_fallback
         else if (raw_rank1_pretest(raw) && raw_is_rank1(raw)) { embed_tile_rank1(y, sw, alpha_k, sc, y); s = 1; }   // closed form as well
-        else if (n2_one_small(n2)) {                                // one singular value out of reach: completed from B, no V
+        else {                                                      // everything else that is flagged: completed from B, no V
           float bb[8][8];
           for (int r = 0; r < 8; ++r) for (int i = 0; i < 8; ++i) bb[r][i] = ab[r >> 1][i][r & 1];
-          embed_tile_one_small(y, bb, sw, alpha_k, sc, y);
+          if (n2_one_small(n2)) embed_tile_one_small(y, bb, sw, alpha_k, sc, y);     // one missing pair: its sign is defined
+          else embed_tile_from_b(y, bb, sw, alpha_k, sc, y);                        // ranks 2 .. 6
         }
-        else s = embed_tile_completed(y, sw, alpha_k, sc);
         for (int r = 0; r < 8; ++r) {
           out.lo[r] = quant_u8(y[r][0]) | (quant_u8(y[r][1]) << 8) | (quant_u8(y[r][2]) << 16) | (quant_u8(y[r][3]) << 24);
           out.hi[r] = quant_u8(y[r][4]) | (quant_u8(y[r][5]) << 8) | (quant_u8(y[r][6]) << 16) | (quant_u8(y[r][7]) << 24);

@@ -310,7 +310,7 @@ def test_rank1_tiles_take_the_closed_form_in_the_plane_path(hh):
     r1 = (rows_eq | cols_eq) & ~(rows_eq & cols_eq)
     assert r1.sum() >= 16 + 2 + 4                                  # the rank-1 block of _degenerate_image + the two edges
     assert not sc.reshape(H // 8, W // 8, 8)[r1][:, 1:].any()      # closed form: exact zeros, not the pattern's delta-sized values
-    rank2 = np.zeros_like(r1); rank2[12:, 4:8] = True              # _degenerate_image's rank-2 block: the literal chain, delta-sized values
+    rank2 = np.zeros_like(r1); rank2[12:, 4:8] = True              # _degenerate_image's rank-2 block: completed from B, Sc = the rounding-sized norms of B's null columns
     assert (sc.reshape(H // 8, W // 8, 8)[rank2][:, 2:] > 0).all()
 
 
