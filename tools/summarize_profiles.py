@@ -14,7 +14,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("k_embed_tiles", "k_embed_fallback", "k_extract_tiles", "k_svd_tiles", "k_sigma_tiles", "k_detect_tiles")
+KERNELS = ("k_embed_tiles", "k_embed_fallback", "k_embed_one_small", "k_extract_tiles", "k_svd_tiles", "k_sigma_tiles", "k_detect_tiles")
 
 
 def short(name):
