@@ -141,6 +141,7 @@ WM_HD void idct8x8(float (&a)[8][8]) {
 constexpr float JAC_TOL2 = 1e-15f;   // skip a rotation below cos = 3.2e-8
 constexpr float JAC_CONV2 = 1e-7f;   // "converged" sweep: max cos < 3.2e-4
 constexpr int JAC_MAX_SWEEPS = 12;
+constexpr int JAC_DEFI_FROM = 6;     // sweeps after which a rank-deficient tile stops counting as "not converged"
 // Singular VALUES alone converge one order ahead of the vectors: after a sweep that saw
 // max cos c the columns are orthogonal to ~c^2 and |b_i| = s_i (1 + O(c^4)), so the
 // sigma-only kernels (extract, detect, K2) may stop at c < 3.2e-2 - their sigma error
@@ -431,6 +432,9 @@ WM_HD int jacobi_cols_pk(v2f (&a)[4][8], float (&n2)[8]) {
 #endif
     jacobi_sweep_pk<SIGMA_ONLY ? 2 : 1>(a, n2, notconv);
     ++sweep;
+    // a rank-deficient tile's null columns are rounding residue whose cosines never fall (and whose tracked norms
+    // cancel to garbage): after JAC_DEFI_FROM sweeps such a lane no longer keeps its wave iterating (gen_jacobi_asm.py)
+    if (sweep >= JAC_DEFI_FROM && !(n2[7] > SIGMA_RATIO_MIN2 * n2[0])) notconv = false;
     more = wave_any(notconv);
   }
   col_norms2_pk(a, n2);

@@ -60,6 +60,8 @@ def _interp(st, n, named, lo=None, hi=None, v_init=None, n_vregs=128):
             x = v[int(tok[1:])]
         elif tok.startswith("s"):
             x = np.full(n, as_f32(s[tok]), F)
+        elif tok.startswith("0x"):                    # 32-bit literal: the bit pattern of a float
+            x = np.full(n, as_f32(int(tok, 16)), F)
         else:
             x = np.full(n, F(float(tok)), F)
         if ab:

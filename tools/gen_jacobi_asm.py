@@ -68,6 +68,7 @@ LAY_V = Lay(40, 168, 184, v0=104, vn0=176)
 # SGPRs (clobbered): mask, sweep counter, constants
 M, SW, EPS, CONV, SKIPC, MINSW, SKIPFROM = "s[80:81]", "s82", "s83", "s84", "s85", "s86", "s87"
 TMPM, NOSKIP, TMPS = "s[88:89]", "s[90:91]", "s92"
+DEFI_FROM = 6           # from this many sweeps on, a lane whose tile is rank deficient no longer keeps its wave iterating
 SAVE = "s[88:89]"       # with-V stream: the caller's exec mask (TMPM / NOSKIP are unused there)
 
 
@@ -262,6 +263,19 @@ def build():
     e(f"s_add_i32 {SW}, {SW}, 1", kind="salu")
     e(f"s_cmp_lt_i32 {SW}, {MINSW}", kind="salu")             # the first sweeps are never the last
     e("s_cbranch_scc1 .Lwmj_sweep_%=", kind="salu")
+    # A rank-deficient tile's null columns are rounding residue: their mutual cosines never fall and their TRACKED norms
+    # cancel to garbage, so such a lane would hold its wave to the sweep bound and report non-convergence on a perfectly
+    # good image (flat-and-gradient UI content: tests/test_gpu_parity.py::test_random_scenes_every_tile_class).  After
+    # DEFI_FROM sweeps - every full-rank tile is long done - a lane with n2[7] <= 1e-10 n2[0] (the tile is flagged and
+    # completed from its good columns anyway) leaves the convergence mask.
+    e(f"s_cmp_lt_i32 {SW}, {DEFI_FROM}", kind="salu")
+    e("s_cbranch_scc1 .Lwmj_nodef_%=", kind="salu")
+    e(f"v_mul_f32_e32 {LAY.x}, 0x{struct.unpack('<I', struct.pack('<f', 1e-10))[0]:08x}, {LAY.N(0)}")
+    e(f"v_mov_b32_e32 {LAY.ih}, {LAY.N(7)}")                    # (keeps the compare's operands one instruction apart)
+    e(f"v_cmp_gt_f32_e32 vcc, {LAY.ih}, {LAY.x}")               # n2[7] > 1e-10 n2[0]: a full-rank tile
+    e(f"s_and_b64 {M}, {M}, vcc", kind="salu")
+    e(".Lwmj_nodef_%=:", kind="label")
+    st.hist.append(("nop", set()))
     e(f"s_cmp_eq_u64 {M}, 0", kind="salu")
     e("s_cbranch_scc1 .Lwmj_done_%=", kind="salu")
     e(f"s_cmp_lt_i32 {SW}, {MAX_SWEEPS}", kind="salu")
