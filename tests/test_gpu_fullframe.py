@@ -356,3 +356,36 @@ def test_fullframe_random_geometries(gpu_ctx):
         for p in range(n):
             so = o.stego_sigma(st[p].astype(np.float32), None)
             assert np.max(np.abs(s2[p] - so)) / so[0] < 3e-6
+
+
+def test_fullframe_random_scenes(gpu_ctx):
+    """Property test of the full-frame mode over generated UI-like scenes (flat areas, rectangles, rules, gradients,
+    saturated patches, texture: planes of any rank): singular values against float64 LAPACK, the reference's invariant
+    svd(Yw)[:K] = Sc[:K] + alpha Sw[:K] (single:174-176) whatever the plane's rank, stego = clip(Yw), detect finite and -
+    for planes with a well separated spectrum - 1 LSB against the float64 chain."""
+    from test_gpu_parity import _scene
+    rng = np.random.default_rng(777)
+    for case in range(8):
+        H = int(rng.choice([64, 96, 128, 200])); W = int(rng.choice([96, 128, 256, 328]))
+        img = _scene(rng, H, W)
+        L = min(H, W)
+        K = max(8, int(float(rng.choice([0.3, 0.6, 1.0])) * L)); alpha = float(rng.uniform(0.05, 0.2))
+        Sw = np.sort(rng.uniform(5, 4000, L).astype(np.float32))[::-1].copy()
+        s64 = np.linalg.svd(img.astype(np.float64), compute_uv=False)
+        sg = gpu_ctx.ref_sigma(img)
+        assert np.abs(sg - s64).max() < 3e-5 * s64[0], (case, np.abs(sg - s64).max() / s64[0])     # null values: residue rows keep their own tiny norm
+        st, sc, yw = gpu_ctx.ref_embed(img, Sw, alpha, K, want_yw=True)
+        assert np.isfinite(yw).all() and np.array_equal(st, np.clip(yw, 0, 255).astype(np.uint8)), case
+        null = s64 < 1e-6 * s64[0]
+        target = np.where(null, 0.0, s64); target[:K] += alpha * Sw[:K].astype(np.float64)
+        s_yw = np.linalg.svd(yw.astype(np.float64), compute_uv=False)
+        err = np.abs(s_yw[:K] - np.sort(target)[::-1][:K]).max() / s_yw[0]
+        assert err < 5e-5, (case, H, W, K, err)
+        score = gpu_ctx.ref_detect(st, sc, Sw, alpha)
+        assert np.isfinite(score), case
+        gaps = np.min(-np.diff(s64[:K]) / s64[0]) if K > 1 else 1.0
+        if s64[min(K, L) - 1] > 1e-4 * s64[0] and gaps > 1e-5:               # the K leading singular vectors are well defined
+            U, S, Vt = np.linalg.svd(img.astype(np.float64), full_matrices=False)
+            ref = img.astype(np.float64) + (U[:, :K] * (alpha * Sw[:K].astype(np.float64))) @ Vt[:K]
+            d = np.abs(np.clip(ref, 0, 255).astype(np.uint8).astype(int) - st.astype(int))
+            assert d.max() <= 1 and np.mean(d != 0) < 5e-3, (case, int(d.max()))
