@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
         h0 = fmaf(w, v.x, h0); h1 = fmaf(w, v.y, h1); h2 = fmaf(w, v.z, h2); h3 = fmaf(w, v.w, h3);
       }
       ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2; ring[s][3] = h3;
-      {                                                    // rows ir - 10 .. ir are in the ring: output row y0 + ir - 10
+      if (ir >= 2 * SH) {                                  // wave-uniform (a scalar branch): the first 10 rows only fill the ring.  Rows ir - 10 .. ir are in the ring: output row y0 + ir - 10
         float m1 = 0.f, m2 = 0.f, e = 0.f, q = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
         const float den = (m11 + m22 + C1) * ((e - m11 - m22) + C2) + 1e-12f;
         const int oy = y0 + ir - 2 * SH;
         const float v = num * __builtin_amdgcn_rcpf(den);
-        acc += (col_ok && ir >= 2 * SH && oy < H) ? v : 0.0f;                              // the first 10 rows only fill the ring
+        acc += (col_ok && oy < H) ? v : 0.0f;
       }
     }
   }
