@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-fullframe", action="store_true", help="skip the full-frame section of the default line")
     ap.add_argument("--quick", action="store_true",
                     help="the contract line only: skip the end-to-end, pool / reference-semantics CPU and full-frame sections")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the rocprofv3 --pmc child passes that measure roofline.traffic / roofline.valu in this run "
+                         "(the committed profile is replayed instead, and labelled so)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a 1-GPU box)")
@@ -484,6 +487,76 @@ def main_fullframe(a):
         dist.destroy_process_group()
 
 
+PMC_SETS = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+            ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]))
+
+
+def live_pmc_section(a, F, H, W, timeout_s=150):
+    """HBM traffic and VALU occupancy of k_embed_tiles measured IN THIS RUN: three child processes, each `rocprofv3
+    --kernel-trace --pmc <one counter set>` round a short `bench.py --quick` of the same shape (separate passes, KiB
+    units and the x2 gfx950 FETCH_SIZE correction as MI355X_MICROARCH.md's HBM section prescribes).  The children are
+    started as ordinary child processes in their own session (never exec'd from this GPU-initialised process), killed
+    as a group on timeout, and anything that goes wrong returns None - the caller then replays the committed profile."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="wm_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    vals, durs = {}, {}
+    try:
+        for tag, counters in PMC_SETS:
+            cmd = [rocprof, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(tmp, tag), "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--quick", "--no-live-pmc", "--steps", "3", "--warmup", "1",
+                   "--cpu-frames", "0", "--frames", str(F), "--height", str(H), "--width", str(W), "--alpha", str(a.alpha)]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None
+            if rc != 0:
+                return None
+            acc = {}
+            for f in glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_embed_tiles" not in r["Kernel_Name"]:
+                        continue
+                    acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+                    acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+                    durs.setdefault(tag, {})[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            for c in counters:
+                if c not in acc or not acc[c]:
+                    return None
+                vals[c] = sum(acc[c].values()) / len(acc[c])          # per launch
+        fetch_b = vals["FETCH_SIZE"] * 1024 * 2                       # KiB; gfx950: FETCH_SIZE reports half of a coalesced read
+        write_b = vals["WRITE_SIZE"] * 1024
+        t = sum(durs["sq"].values()) / len(durs["sq"]) * 1e-9
+        clk = vals["GRBM_GUI_ACTIVE"] / 8 / t                          # summed over the 8 XCDs
+        n_waves = F * (((H // 8) * (W // 8) + 63) // 64)
+        return {"traffic": fetch_b + write_b, "fetch_bytes_x2_corrected": fetch_b, "write_bytes": write_b,
+                "valu": {"busy_frac_pmc": vals["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t * clk),
+                         "insts_per_64_tile_wave": vals["SQ_INSTS_VALU"] / n_waves, "effective_clock_GHz": clk / 1e9,
+                         "kernel_us_under_pmc": t * 1e6,
+                         "source": "measured in this run: child `rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU "
+                                   "SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` pass of `bench.py --quick` at this shape"},
+                "traffic_source": "measured in this run: child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes "
+                                  "(one each) of `bench.py --quick` at this shape, per k_embed_tiles launch; FETCH_SIZE x 1024 x 2 "
+                                  "(gfx950 correction, an upper bound for our 4-8 B/lane reads) + WRITE_SIZE x 1024"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def launch_ranks(a) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes
     (torch.distributed.run, rendezvous on 127.0.0.1) from this parent, which has not imported
@@ -642,6 +715,16 @@ def main():
                                       f"not measured in this run"}
             except Exception:
                 traffic = None
+        live = None
+        if world == 1 and not a.quick and not a.no_live_pmc:
+            t_l = time.perf_counter()
+            live = live_pmc_section(a, F, H, W)
+            if live is not None:
+                traffic, traffic_source, valu = live["traffic"], live["traffic_source"], live["valu"]
+                valu["fetch_bytes_x2_corrected"] = live["fetch_bytes_x2_corrected"]; valu["write_bytes"] = live["write_bytes"]
+                valu["collection_s"] = time.perf_counter() - t_l
+            elif traffic_source is not None:
+                traffic_source = "live rocprofv3 passes failed or timed out in this run; " + traffic_source
         out = {
             "metric": "frames/sec embed+extract @4K Y-channel",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
