@@ -224,7 +224,8 @@ def unpermute(plane: np.ndarray, idx: np.ndarray) -> np.ndarray:
 def hmac_digest(key: bytes, arrays) -> bytes:
     h = _hmac.new(key, b"", hashlib.sha256)
     for a in arrays:
-        h.update(np.ascontiguousarray(a).tobytes())
+        # the array's own bytes (the reference's `.tobytes()`, single:82-86) fed as a buffer: no 33 MB copy per factor at 4K
+        h.update(np.ascontiguousarray(a).reshape(-1).view(np.uint8))
     return h.digest()
 
 
