@@ -54,14 +54,78 @@ __device__ __forceinline__ uint32_t byte_of(const uint32_t (&w)[12], const int i
   return (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
 }
 
+// one group of 16 pixels: w = its 48 interleaved input bytes, pl = 16 plane bytes (replace-Y only) -> o (48 interleaved
+// output bytes) or po (16 plane bytes)
+template <int OP>
+__device__ __forceinline__ void color_group(const uint32_t (&w)[12], const uint32_t (&pl)[4], uint32_t (&o)[12], uint32_t (&po)[4]) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) o[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) po[i] = 0;
+#pragma unroll
+  for (int px = 0; px < 16; ++px) {
+    const uint32_t c0 = byte_of(w, 3 * px), c1 = byte_of(w, 3 * px + 1), c2 = byte_of(w, 3 * px + 2);
+    uint32_t a0 = 0, a1 = 0, a2 = 0, p1 = 0;
+    if (OP == BGR_TO_YCC) bgr2ycc(c0, c1, c2, a0, a1, a2);
+    else if (OP == YCC_TO_BGR) ycc2bgr(c0, c1, c2, a0, a1, a2);
+    else if (OP == BGR_TO_GRAY) p1 = bgr2gray(c0, c1, c2);
+    else if (OP == BGR_TO_Y) { uint32_t cr, cb; bgr2ycc(c0, c1, c2, p1, cr, cb); }
+    else {  // replace Y of the BGR pixel's YCrCb by the plane value, convert back (single:26-30)
+      uint32_t y, cr, cb; bgr2ycc(c0, c1, c2, y, cr, cb);
+      const uint32_t ynew = (pl[px >> 2] >> (8 * (px & 3))) & 0xffu;
+      ycc2bgr(ynew, cr, cb, a0, a1, a2);
+    }
+    if (OP == BGR_TO_GRAY || OP == BGR_TO_Y) po[px >> 2] |= p1 << (8 * (px & 3));
+    else {
+      o[(3 * px) >> 2] |= a0 << (8 * ((3 * px) & 3));
+      o[(3 * px + 1) >> 2] |= a1 << (8 * ((3 * px + 1) & 3));
+      o[(3 * px + 2) >> 2] |= a2 << (8 * ((3 * px + 2) & 3));
+    }
+  }
+}
+
 // generic over pixel groups: in3 = interleaved 3-channel input (16 px = 48 B), plane = single-channel
 // input/output (16 B per group), out3 = interleaved 3-channel output
 template <int OP>
 __global__ __launch_bounds__(256) void k_color(const uint8_t* __restrict__ in3, const uint8_t* __restrict__ plane_in,
                                               uint8_t* __restrict__ out3, uint8_t* __restrict__ plane_out,
                                               const size_t n_px) {
+  constexpr bool OUT3 = !(OP == BGR_TO_GRAY || OP == BGR_TO_Y);
   const size_t n_groups = n_px / 16;
-  for (size_t gidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < n_groups;
+  auto load_group = [&](const size_t gidx, uint32_t (&w)[12], uint32_t (&pl)[4]) {
+    // the thread's own 48 bytes (a line is shared by three load instructions of the wave; nothing is fetched twice)
+    const uint4* src = reinterpret_cast<const uint4*>(in3 + gidx * 48);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const uint4 v = src[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+    pl[0] = pl[1] = pl[2] = pl[3] = 0;
+    if (OP == Y_INTO_YCC_TO_BGR) {
+      const uint4 v = *reinterpret_cast<const uint4*>(plane_in + gidx * 16);
+      pl[0] = v.x; pl[1] = v.y; pl[2] = v.z; pl[3] = v.w;
+    }
+  };
+  // Interleaved 3-channel OUTPUT leaves the workgroup as whole 16-byte chunks in address order (a wave's store instruction
+  // covers 1 KiB contiguous): the thread that owns a 16-pixel group puts its 48 bytes - chunks 3t .. 3t + 2 of the block's
+  // 12 KiB - into LDS (ds_write_b128 at a 48-byte lane stride: conflict-free) and the block stores the chunks in order.
+  // Direct stores of the own 48 bytes touch 24 lines per wave instruction for 1 KiB of data: BGR -> YCrCb 59 -> 67 % of
+  // 8 TB/s, replace-Y 63 -> 66 % (profiles/r03y_color_lds.log).  The same staging on the LOAD side changes nothing or costs
+  // (BGR -> Y 77 -> 76 %): the loads stay direct, and so do the 16-byte plane stores.
+  __shared__ uint4 stage[OUT3 ? 3 * 256 : 1];
+  const size_t n_full = OUT3 ? n_groups / 256 : 0;       // whole blocks of 256 groups; the rest takes the direct form below
+  for (size_t blk = blockIdx.x; blk < n_full; blk += gridDim.x) {
+    uint32_t w[12], pl[4], o[12], po[4];
+    load_group(blk * 256 + threadIdx.x, w, pl);
+    color_group<OP>(w, pl, o, po);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) stage[3 * threadIdx.x + i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(out3 + blk * 256 * 48);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dst[i * 256 + threadIdx.x] = stage[i * 256 + threadIdx.x];
+    __syncthreads();                                     // the next block's groups overwrite stage
+  }
+  // groups outside whole blocks, and every group of the single-plane outputs: the direct form (kept literally as it was -
+  // through the shared helpers the BGR -> Y loop came out at 44 instead of 61 VGPRs and 71 instead of 78 % of 8 TB/s)
+  for (size_t gidx = n_full * 256 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < n_groups;
        gidx += (size_t)gridDim.x * blockDim.x) {
     uint32_t w[12];
     const uint4* src = reinterpret_cast<const uint4*>(in3 + gidx * 48);
