@@ -34,6 +34,10 @@ def main():
     rng = np.random.default_rng(3)
     bgr = rng.integers(0, 256, (n, 3), dtype=np.uint8)
     ypl = rng.integers(0, 256, n, dtype=np.uint8)
+    fpl = rng.normal(0, 50, n).astype(np.float32)
+    hg = importlib.import_module(api.__name__.rsplit(".", 1)[0] + ".hostglue")
+    npl = a.H * a.W
+    idx = hg.permutation_index(a.H, a.W, hg.derive_key("bench", bytes(8))) if a.odd == 0 else None
     vp = api._vp
     V = []
     for path in a.libs:
@@ -47,6 +51,13 @@ def main():
             bgr2ycc=(lambda d=d, c=c: c._call("wm_bgr_to_ycrcb_u8_dev", vp(d["bgr"]), vp(d["o3"]), n), 6.0 * n, "o3"),
             bgr2y=(lambda d=d, c=c: c._call("wm_bgr_to_y_u8_dev", vp(d["bgr"]), vp(d["o1"]), n), 4.0 * n, "o1"),
             replace_y=(lambda d=d, c=c: c._call("wm_replace_y_u8_dev", vp(d["bgr"]), vp(d["y"]), vp(d["o3"]), n), 7.0 * n, "o3"))
+        d["f"] = c.malloc(n * 4); c.h2d(d["f"], fpl)
+        d["ops"]["minmax_norm"] = (lambda d=d, c=c: [c._call("wm_normalize_u8_dev", vp(d["f"] + z * npl * 4), npl, 1, vp(d["o1"] + z * npl))
+                                                     for z in range(max(1, n // npl))], 9.0 * (n // npl) * npl, "o1")
+        if idx is not None:
+            d["route"] = c.route_dev(idx)
+            d["ops"]["unscr_norm_routed"] = (lambda d=d, c=c: c._call("wm_unpermute_normalize_u8_dev", vp(d["f"]), vp(d["route"]), vp(d["o1"]), npl, a.frames, 1),
+                                             13.0 * n, "o1")
         d["t"] = {k: [] for k in d["ops"]}
         V.append(d)
     ref = {}
