@@ -1305,26 +1305,35 @@ int ref_embed_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t*
 // extract of B planes: sigma(stego) -> Sw_hat -> Uw[:L,:L] diag(Sw_hat) Vwt[:L,:L], zero-padded -> idct2.
 // d_uw [H][L] and d_vwt [L][W] are the meta factors on the device (leading dimensions L and W);
 // sigma_c HOST [B][L]; d_out dense float [B][H][W].  ws: tmp1 = Uw diag(sh) [B][L][L], tmp2 tail = GEMM intermediate [B][H][W].
+// the product and the inverse DCT of single:214-218 for B planes with the estimates given: sh HOST [B][p.Lp] (entries at and
+// beyond Lx are not read), Lx <= p.L the reference's truncation length - Uw[:Lx,:Lx] diag(sh) Vwt[:Lx,:Lx] lands in the
+// top-left Lx x Lx corner of the zero plane (single:215-217), then idct2 of the whole H x W plane.
+int ref_reconstruct_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const std::vector<float>& sh, const int Lx,
+                         const float* d_uw, const float* d_vwt, float* d_us, float* d_mid, float* d_out) {
+  const int L = p.L, H = p.H, W = p.W;
+  WM_HIP(hipMemcpyAsync(w.dvec, sh.data(), sh.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  float *dH, *dW;
+  WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
+  // Uw[:Lx,:Lx] * sh (column scaling) per plane: the first Lx rows of Uw (leading dimension L)
+  hipLaunchKernelGGL(k_rf_scale_cols_b, dim3(8, Lx, p.B), dim3(256), 0, ctx->stream, d_uw, (size_t)0, d_us, (size_t)L * L, L,
+                     w.dvec, (size_t)p.Lp);
+  WM_HIP(hipMemsetAsync(d_out, 0, (size_t)p.B * H * W * 4, ctx->stream));                                     // single:215
+  WM_TRY(sgemm_b(ctx, false, false, Lx, Lx, Lx, 1.0f, d_us, L, (size_t)L * L, d_vwt, W, 0, 0.0f, d_out, W, (size_t)H * W, p.B));  // single:214, 216-217 (Vwt[:L,:L]: ld W)
+  WM_TRY(sgemm_b(ctx, true, false, H, W, H, 1.0f, dH, H, 0, d_out, W, (size_t)H * W, 0.0f, d_mid, W, (size_t)H * W, p.B));   // idct2: D_H^T X
+  WM_TRY(sgemm_b(ctx, false, false, H, W, W, 1.0f, d_mid, W, (size_t)H * W, dW, W, 0, 0.0f, d_out, W, (size_t)H * W, p.B));  //        ... D_W   single:218
+  WM_HIP(hipStreamSynchronize(ctx->stream));         // sh may be a local of the caller
+  return WM_OK;
+}
+
 int ref_extract_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* s_cw, const float* sigma_c,
                      const float* d_uw, const float* d_vwt, float* d_us, float* d_mid, float* d_out, float alpha, int K) {
-  const int L = p.L, H = p.H, W = p.W;
+  const int L = p.L;
   const float a = fmaxf(alpha, 1e-8f);
   std::vector<float> sh((size_t)p.B * p.Lp, 0.0f);
   for (int z = 0; z < p.B; ++z)
     for (int i = 0; i < K; ++i)
       sh[(size_t)z * p.Lp + i] = (s_cw[(size_t)z * L + i] - sigma_c[(size_t)z * L + i]) / a;                  // single:212-213
-  WM_HIP(hipMemcpyAsync(w.dvec, sh.data(), sh.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  float *dH, *dW;
-  WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
-  // Uw[:L,:L] * sh (column scaling) per plane: the first L rows of Uw (leading dimension L)
-  hipLaunchKernelGGL(k_rf_scale_cols_b, dim3(8, L, p.B), dim3(256), 0, ctx->stream, d_uw, (size_t)0, d_us, (size_t)L * L, L,
-                     w.dvec, (size_t)p.Lp);
-  WM_HIP(hipMemsetAsync(d_out, 0, (size_t)p.B * H * W * 4, ctx->stream));                                     // single:215
-  WM_TRY(sgemm_b(ctx, false, false, L, L, L, 1.0f, d_us, L, (size_t)L * L, d_vwt, W, 0, 0.0f, d_out, W, (size_t)H * W, p.B));  // single:214, 216-217 (Vwt[:L,:L]: ld W)
-  WM_TRY(sgemm_b(ctx, true, false, H, W, H, 1.0f, dH, H, 0, d_out, W, (size_t)H * W, 0.0f, d_mid, W, (size_t)H * W, p.B));   // idct2: D_H^T X
-  WM_TRY(sgemm_b(ctx, false, false, H, W, W, 1.0f, d_mid, W, (size_t)H * W, dW, W, 0, 0.0f, d_out, W, (size_t)H * W, p.B));  //        ... D_W   single:218
-  WM_HIP(hipStreamSynchronize(ctx->stream));         // sh is a local
-  return WM_OK;
+  return ref_reconstruct_core(ctx, p, w, sh, L, d_uw, d_vwt, d_us, d_mid, d_out);
 }
 
 double nc_score(const float* sw, const float* scw, const float* sc, int L, float alpha) {
@@ -1612,6 +1621,34 @@ int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, c
                       float* out, int H, int W, int row_stride, float alpha, int K) {
   return wm_ref_extract_planes_u8(ctx, stego, sigma_c, Uw, Vwt, out, 1, H, W, row_stride, (size_t)H * row_stride,
                                   alpha, K);
+}
+
+// single:214-218 on its own, with the estimates given: the drop-in uses it when the stego's size is not the meta's (a
+// resized or cropped stego - the reference goes on with L = the shortest of the four lengths, single:210)
+int wm_ref_reconstruct_f32(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt, float* out, int H, int W,
+                           int L) {
+  WM_TRY(check_ref_args(ctx, Uw, 1, H, W, W, (size_t)H * W));
+  if (!sw_hat || !Vwt || !out) return set_err(WM_ERR_BADARG, "NULL argument");
+  const RefPlan p = make_plan(H, W, 1);
+  const int Lm = p.L;
+  if (L < 0 || L > Lm) return set_err(WM_ERR_BADARG, "L must be in 0..min(H,W)");
+  RefWs w;
+  // tmp1: Uw[:Lm,:Lm] | Vwt [Lm][W] | Uw diag(sh) [Lm][Lm] | result [H][W];  tmp2: GEMM intermediate [H][W]
+  WM_TRY(plan_workspace(ctx, p, w, 2 * (size_t)Lm * Lm + (size_t)Lm * W + (size_t)H * W + 16, (size_t)H * W));
+  float* d_u = w.tmp1; float* d_v = d_u + (size_t)Lm * Lm; float* d_us = d_v + (size_t)Lm * W;
+  float* d_full = d_us + (size_t)Lm * Lm;
+  WM_HIP(hipMemcpyAsync(d_u, Uw, (size_t)Lm * Lm * 4, hipMemcpyHostToDevice, ctx->stream));          // Uw[:Lm,:Lm] (H x Lm, rows < Lm)
+  WM_HIP(hipMemcpyAsync(d_v, Vwt, (size_t)Lm * W * 4, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<float> sh((size_t)p.Lp, 0.0f);
+  for (int i = 0; i < L; ++i) sh[i] = sw_hat[i];
+  if (L == 0) {
+    WM_HIP(hipMemsetAsync(d_full, 0, (size_t)H * W * 4, ctx->stream));       // idct2 of the zero plane
+  } else {
+    WM_TRY(ref_reconstruct_core(ctx, p, w, sh, L, d_u, d_v, d_us, w.tmp2, d_full));
+  }
+  WM_HIP(hipMemcpyAsync(out, d_full, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
 }
 
 // outer sweeps the last full-frame SVD on this context took (for flop accounting)

@@ -179,11 +179,45 @@ def _meta_tile(meta) -> Optional[int]:
 
 
 def _check_stego_shape(stego: np.ndarray, meta):
-    """A meta belongs to one stego size (the reference fails later, inside NumPy, with a
-    reshape / matmul error; here the mismatch is named before any device call)."""
+    """Tile mode: a meta belongs to one stego size (per-tile factors; the mismatch is named before any
+    device call).  Full-frame mode follows the reference, which goes on with the shortest of the
+    lengths involved (single:210, 299) - see _extract_resized / _detect_resized."""
     H, W = map(int, meta["shape"])
     if tuple(stego.shape[:2]) != (H, W):
         raise ValueError(f"stego is {stego.shape[1]}x{stego.shape[0]} but the meta was written for {W}x{H}")
+
+
+def _same_size(stego: np.ndarray, meta) -> bool:
+    H, W = map(int, meta["shape"])
+    return tuple(stego.shape[:2]) == (H, W)
+
+
+def _extract_plane_resized(ctx, plane_u8, Sc, Uw, Vwt, alpha, kfrac, k_floor, H, W):
+    """single:205-218 for a stego plane whose size is not the meta's (a resized or cropped stego): the
+    reference does not look at the size - sigma of whatever plane it was given, L = the shortest of the four
+    lengths, the [:L,:L] corner of the meta's factors, the META's H x W for the zero plane and the permutation."""
+    S_cw = ctx.ref_sigma(plane_u8)                                         # single:205
+    Sc = np.asarray(Sc, dtype=np.float32)
+    L = min(len(Sc), len(S_cw), Uw.shape[0], Vwt.shape[0])                 # single:210
+    K = _k_of(L, kfrac, k_floor)                                           # single:211
+    sw_hat = ((S_cw[:L] - Sc[:L]) / np.float32(max(alpha, 1e-8))).astype(np.float32)   # single:212
+    sw_hat[K:] = 0                                                         # single:213
+    return ctx.ref_reconstruct(Uw, sw_hat, Vwt, H, W)                      # single:214-218
+
+
+def _nc(a, b) -> float:
+    """single:284-289"""
+    a = np.asarray(a, dtype=np.float32).reshape(-1); b = np.asarray(b, dtype=np.float32).reshape(-1)
+    a = a - a.mean(); b = b - b.mean()
+    return float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-8))
+
+
+def _detect_plane_resized(ctx, plane_u8, Sc, Sw, alpha) -> float:
+    """single:297-301 when the three vectors differ in length: truncated to the shortest (single:299)."""
+    S_cw = ctx.ref_sigma(plane_u8)
+    Sc = np.asarray(Sc, dtype=np.float32).reshape(-1); Sw = np.asarray(Sw, dtype=np.float32).reshape(-1)
+    L = min(len(Sc), len(S_cw), len(Sw))
+    return _nc(Sw[:L], (S_cw[:L] - Sc[:L]) / np.float32(max(alpha, 1e-8)))
 
 
 def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = True,
@@ -208,7 +242,8 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
     if not hg.digests_equal(hg.hmac_digest(key, parts), digest):
         raise ValueError("Sai mật khẩu hoặc meta không khớp.")             # single:208-209,246-247
     tile = _meta_tile(meta)
-    _check_stego_shape(stego, meta)
+    if tile is not None:
+        _check_stego_shape(stego, meta)
     ctx = _ctx(device)
     idx = hg.permutation_index(H, W, key)                                  # single:219,265
     if tile is None:
@@ -230,16 +265,23 @@ def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, 
     def k_for(Sc, S_len_u, S_len_v):
         L = min(len(Sc), min(H, W), S_len_u, S_len_v)                      # single:210
         return _k_of(L, kfrac, k_floor)
+    same = _same_size(stego, meta)            # a stego of another size: the reference's truncation rules, single:210
     if mode == "gray":
         Y = ctx.color("bgr2y", stego)
         Uw, Vwt = meta["Uw"], meta["Vwt"]
-        wy_s = ctx.ref_extract(Y, meta["Sc"], Uw, Vwt, alpha, k_for(meta["Sc"], Uw.shape[0], Vwt.shape[0]))
+        if same:
+            wy_s = ctx.ref_extract(Y, meta["Sc"], Uw, Vwt, alpha, k_for(meta["Sc"], Uw.shape[0], Vwt.shape[0]))
+        else:
+            wy_s = _extract_plane_resized(ctx, Y, meta["Sc"], Uw, Vwt, alpha, kfrac, k_floor, H, W)
         return ctx.unpermute_normalize_u8(wy_s, idx, normalize)
     outs = []
     for ch, n in enumerate("bgr"):
         U, Vt, Sc = meta["UW" + n], meta["VW" + n + "t"], meta["S" + n]
-        w_s = ctx.ref_extract(np.ascontiguousarray(stego[..., ch]), Sc, U, Vt, alpha,
-                              k_for(Sc, U.shape[0], Vt.shape[0]))
+        plane = np.ascontiguousarray(stego[..., ch])
+        if same:
+            w_s = ctx.ref_extract(plane, Sc, U, Vt, alpha, k_for(Sc, U.shape[0], Vt.shape[0]))
+        else:
+            w_s = _extract_plane_resized(ctx, plane, Sc, U, Vt, alpha, kfrac, k_floor, H, W)
         outs.append(ctx.unpermute_normalize_u8(w_s, idx, normalize))
     return np.stack(outs, axis=-1)
 
@@ -247,14 +289,18 @@ def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, 
 def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0):
     mode = str(meta["mode"]); alpha = float(meta["alpha"])                 # single:293
     tile = _meta_tile(meta)
-    _check_stego_shape(stego, meta)
+    if tile is not None:
+        _check_stego_shape(stego, meta)
     ctx = _ctx(device)
     if tile is None:
+        same = _same_size(stego, meta)        # another size: the vectors are cut to the shortest, single:299,311-313
         if mode == "gray":
             Y = ctx.color("bgr2y", stego)
-            score = ctx.ref_detect(Y, meta["Sc"], meta["Sw"], alpha)       # single:297-301
+            score = (ctx.ref_detect(Y, meta["Sc"], meta["Sw"], alpha) if same                 # single:297-301
+                     else _detect_plane_resized(ctx, Y, meta["Sc"], meta["Sw"], alpha))
             return bool(score >= thresh), float(score)
-        nc = [ctx.ref_detect(np.ascontiguousarray(stego[..., ch]), meta["S" + n], meta["SW" + n], alpha)
+        nc = [ctx.ref_detect(np.ascontiguousarray(stego[..., ch]), meta["S" + n], meta["SW" + n], alpha) if same
+              else _detect_plane_resized(ctx, np.ascontiguousarray(stego[..., ch]), meta["S" + n], meta["SW" + n], alpha)
               for ch, n in enumerate("bgr")]                               # single:304-316
         score = float((nc[0] + nc[1] + nc[2]) / 3.0)
         return bool(score >= thresh), score

@@ -85,6 +85,7 @@ SIGNATURES = {
     "wm_ref_svd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_extract_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f, _i],
+    "wm_ref_reconstruct_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "wm_ref_detect_u8": [_vp, _vp, _vp, _vp, C.POINTER(C.c_double), _i, _i, _i, _f],
     "wm_ref_detect_planes_u8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f],
     "wm_bgr_to_ycrcb_u8_dev": [_vp, _vp, _vp, _sz],
@@ -496,6 +497,21 @@ class Context:
         out = np.empty((H, W), np.float32)
         self._call("wm_ref_extract_u8", _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(Uw.ctypes.data),
                    _vp(Vwt.ctypes.data), _vp(out.ctypes.data), H, W, W, float(alpha), int(K))
+        return out
+
+    def ref_reconstruct(self, Uw, sw_hat, Vwt, H: int, W: int) -> np.ndarray:
+        """single:214-218 with the estimates given: ``Uw[:L,:L] @ diag(sw_hat) @ Vwt[:L,:L]`` (L = len(sw_hat)) in the
+        top-left corner of a zero H x W plane, then idct2.  Uw [H, min(H,W)], Vwt [min(H,W), W] as the meta holds them."""
+        Lm = min(H, W)
+        Uw = np.ascontiguousarray(Uw, dtype=np.float32); Vwt = np.ascontiguousarray(Vwt, dtype=np.float32)
+        sh = np.ascontiguousarray(sw_hat, dtype=np.float32).reshape(-1)
+        if Uw.shape != (H, Lm) or Vwt.shape != (Lm, W):
+            raise ValueError(f"Uw {Uw.shape} / Vwt {Vwt.shape} are not the factors of a {H}x{W} plane")
+        if sh.size > Lm:
+            raise ValueError(f"{sh.size} estimates for a plane with {Lm} singular values")
+        out = np.empty((H, W), np.float32)
+        self._call("wm_ref_reconstruct_f32", _vp(Uw.ctypes.data), _vp(sh.ctypes.data) if sh.size else _vp(out.ctypes.data),
+                   _vp(Vwt.ctypes.data), _vp(out.ctypes.data), H, W, int(sh.size))
         return out
 
     def ref_extract_planes(self, stegos: np.ndarray, sigma_c, Uw, Vwt, alpha: float, K: int) -> np.ndarray:

@@ -220,6 +220,17 @@ int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* V
 int wm_ref_extract_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* Uw,
                       const float* Vwt, float* out, int H, int W, int row_stride, float alpha, int K);
 
+/* Replaces single:214-218 on their own, with the estimates given by the caller:
+ * Uw[:L,:L] @ diag(sw_hat[:L]) @ Vwt[:L,:L] into the top-left corner of a zero H x W plane
+ * (single:215-217), then idct2 (single:218).  L <= min(H, W) is the reference's truncation
+ * length `min(len(Sc), len(S_cw), Uw.shape[0], Vwt.shape[0])` (single:210): it is shorter than
+ * the meta's own when the stego handed to extract is not the size the meta was written for
+ * (resized / cropped stego) - the drop-in then takes sigma of the stego with wm_ref_sigma_u8,
+ * forms Sw_hat on the host (single:211-213) and calls this.
+ *   Uw [H][min(H,W)], sw_hat [L], Vwt [min(H,W)][W], out [H][W] float32, all host memory. */
+int wm_ref_reconstruct_f32(wm_ctx* ctx, const float* Uw, const float* sw_hat, const float* Vwt, float* out,
+                           int H, int W, int L);
+
 /* The same for n_planes stego planes that share ONE watermark decomposition (the frames
  * of a clip, single:205-218 applied per frame): their SVDs run as one batch.
  *   sigma_c [n_planes][L], out [n_planes][H][W] float32. */

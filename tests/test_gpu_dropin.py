@@ -351,3 +351,64 @@ def test_array_level_roundtrip_on_generated_scenes(core, tile):
             a = w.astype(np.float64).ravel(); b = w_o.astype(np.float64).ravel()
             if a.std() > 0 and b.std() > 0:
                 assert np.corrcoef(a, b)[0, 1] > 0.5, (case, color, tile, np.corrcoef(a, b)[0, 1])
+
+
+@pytest.mark.parametrize("color", [False, True], ids=["gray", "colour"])
+def test_fullframe_resized_stego_follows_the_reference(core, color):
+    """A stego that is not the size its meta was written for (cropped, padded or rescaled - the usual robustness
+    experiment).  The reference does not look at the size: extract takes sigma of whatever plane it is given, cuts to
+    L = min(len(Sc), len(S_cw), Uw.shape[0], Vwt.shape[0]), uses the [:L,:L] corner of the meta's factors and the
+    META's H x W for the zero plane and the permutation (single:205-220); detect cuts the vectors to the shortest
+    (single:299).  The drop-in must do the same (it raised ValueError until round 3b); oracle = restatement of those lines."""
+    rng = np.random.default_rng(77)
+    H, W = 96, 128
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = 110 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+    cover = np.clip(base[..., None] + rng.normal(0, 12, (H, W, 3)), 0, 255).astype(np.uint8)
+    wm = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    nonce = bytes(range(8))
+    r = core.embed_arrays(cover, wm, "pw", nonce, 0.15, color, 0.6, None, 8)
+    stego, meta = r["stego"], r["meta"]
+    same = core.extract_arrays(stego, meta, "pw", True)
+    variants = {
+        "cropped": np.ascontiguousarray(stego[8:88, 10:122]),                                   # 80 x 112: L = 80 < 96
+        "padded": np.pad(stego, ((0, 16), (0, 32), (0, 0)), mode="edge"),                       # 112 x 160: L stays 96
+        "tall": np.ascontiguousarray(np.repeat(stego, 2, axis=0)[:160, :100]),                  # 160 x 100: transposed aspect
+    }
+    for name, st in variants.items():
+        ex_o = o.extract_arrays(st, meta, "pw", True, None, 8)
+        ex_g = core.extract_arrays(st, meta, "pw", True)
+        assert ex_g.shape == ex_o.shape == same.shape, name          # the META's size, whatever the stego's
+        d = np.abs(ex_g.astype(int) - ex_o.astype(int))
+        assert np.mean(d > 2) < 2e-2, (name, float(np.mean(d > 2)), int(d.max()))
+        ok_o, sc_o = o.detect_arrays(st, meta, 0.6, None)
+        ok_g, sc_g = core.detect_arrays(st, meta, 0.6)
+        assert abs(sc_g - sc_o) < 2e-3 and ok_g == ok_o, (name, sc_g, sc_o)
+    # the same-size path is untouched by the new branch
+    ex_o = o.extract_arrays(stego, meta, "pw", True, None, 8)
+    assert np.mean(np.abs(same.astype(int) - ex_o.astype(int)) > 2) < 2e-2
+    # tile mode still names the mismatch (its meta holds per-tile factors of one size)
+    r8 = core.embed_arrays(cover, wm, "pw", nonce, 0.15, color, 0.6, 8, 8)
+    with pytest.raises(ValueError, match="meta was written for"):
+        core.extract_arrays(variants["cropped"], r8["meta"], "pw", True)
+    with pytest.raises(ValueError, match="meta was written for"):
+        core.detect_arrays(variants["cropped"], r8["meta"], 0.6)
+
+
+def test_ref_reconstruct_against_numpy(gpu_ctx):
+    """wm_ref_reconstruct_f32 = single:214-218 with the estimates given, for L below, at and above nothing: the [:L,:L]
+    corner of the factors, zero elsewhere, idct2 of the whole plane."""
+    rng = np.random.default_rng(5)
+    for (H, W) in ((64, 96), (96, 64), (48, 48)):
+        Lm = min(H, W)
+        Uw = rng.normal(0, 1, (H, Lm)).astype(np.float32); Vwt = rng.normal(0, 1, (Lm, W)).astype(np.float32)
+        for L in (0, 1, Lm // 2 + 1, Lm):
+            sh = rng.normal(0, 30, L).astype(np.float32)
+            full = np.zeros((H, W), np.float64)
+            full[:L, :L] = (Uw[:L, :L].astype(np.float64) * sh.astype(np.float64)) @ Vwt[:L, :L].astype(np.float64)
+            want = o.idct2(full.astype(np.float32))
+            got = gpu_ctx.ref_reconstruct(Uw, sh, Vwt, H, W)
+            assert got.shape == (H, W)
+            assert np.max(np.abs(got - want)) <= 2e-4 * max(1.0, float(np.abs(want).max())), (H, W, L)
+    with pytest.raises(ValueError):
+        gpu_ctx.ref_reconstruct(Uw, np.zeros(Lm + 1, np.float32), Vwt, H, W)
