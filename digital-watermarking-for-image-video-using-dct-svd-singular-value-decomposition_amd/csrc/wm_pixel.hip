@@ -280,12 +280,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
   auto row_of = [&](const int ir) { return refl(min(y0 - SH + ir, H + SH - 1), H); };
   // PF rows in flight ahead of the one being worked on (register ring with static indices, like the sums)
   float am[11], bm[11], ah[11], bh[11];
+  // buffer loads: one resource per image, the lane's column as the VGPR offset, the row as the SGPR offset - no 64-bit
+  // address arithmetic per row (34 -> 12 SALU and 4 fewer VALU instructions per row); planes are < 2 GiB (checked on the host)
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)img1, 0, (int)(((size_t)(H - 1) * s1 + W) * sizeof(TA)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)img2, 0, (int)(((size_t)(H - 1) * s2 + W) * sizeof(TB)), 0x00020000);
+  const unsigned row1 = (unsigned)(s1 * sizeof(TA)), row2 = (unsigned)(s2 * sizeof(TB));
+  auto ld1 = [&](const unsigned col, const unsigned roff) -> float {
+    if constexpr (sizeof(TA) == 1) return (float)__builtin_amdgcn_raw_buffer_load_b8(rs1, col, roff, 0);
+    else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, col * 4u, roff, 0));
+  };
+  auto ld2 = [&](const unsigned col, const unsigned roff) -> float {
+    if constexpr (sizeof(TB) == 1) return (float)__builtin_amdgcn_raw_buffer_load_b8(rs2, col, roff, 0);
+    else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, col * 4u, roff, 0));
+  };
 #define SSIM_FETCH(slot, ir)                                                               \
   do {                                                                                     \
-    const size_t gy_ = (size_t)row_of(ir);                                                 \
-    const TA* r1_ = img1 + gy_ * s1; const TB* r2_ = img2 + gy_ * s2;                      \
-    am[slot] = (float)r1_[gxm]; bm[slot] = (float)r2_[gxm];                                \
-    ah[slot] = (float)r1_[gxh]; bh[slot] = (float)r2_[gxh];                                \
+    const unsigned gy_ = (unsigned)row_of(ir);                                             \
+    const unsigned o1_ = gy_ * row1, o2_ = gy_ * row2;                                     \
+    am[slot] = ld1(gxm, o1_); bm[slot] = ld2(gxm, o2_);                                    \
+    ah[slot] = ld1(gxh, o1_); bh[slot] = ld2(gxh, o2_);                                    \
   } while (0)
 #ifndef WM_SSIM_PREFETCH
 #define WM_SSIM_PREFETCH 3
@@ -294,7 +307,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
 #pragma unroll                                           // that NOTHING in the row loop branches per lane: with the halo loads and
   for (int r = 0; r < PF; ++r) SSIM_FETCH(r, r);         // stores under `if (lane < 10)` hipcc closed every block with vmcnt(0) and
                                                          // the prefetch was void (68 us per 4K plane, as slow as the tiled form)
-  float ring[11][4];
+  // the two field pairs (x, y) and (x^2 + y^2, xy) as explicit 2-vectors: every tap is one v_pk_fma_f32 per pair.  Left to
+  // the SLP vectoriser, 24 of a row's 94 FMAs stayed scalar `v_fmac_f32 v, s, v` - which costs 1.9 ns per wave-instruction
+  // with its SGPR tap, as much as a packed one that does two (tools/ubench_ssim_fma.hip, profiles/r03y_ubench_ssim_fma.log)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 ringA[11], ringB[11];
   float acc = 0.0f;
   const float C1 = (0.01f * 255) * (0.01f * 255), C2 = (0.03f * 255) * (0.03f * 255);
   const bool col_ok = x0 + lane < W;
@@ -318,22 +335,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
       // of rb[lane] (different addresses per lane).  A scheduling barrier costs nothing; s_waitcnt + s_barrier did.
       __builtin_amdgcn_wave_barrier();
 #endif
-      float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+      f2 hA = {0.f, 0.f}, hB = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
         const float4 v = rb[lane + k];
-        const float w = taps.w[k];
-        h0 = fmaf(w, v.x, h0); h1 = fmaf(w, v.y, h1); h2 = fmaf(w, v.z, h2); h3 = fmaf(w, v.w, h3);
+        const f2 w2 = {taps.w[k], taps.w[k]};
+        hA = __builtin_elementwise_fma(w2, (f2){v.x, v.y}, hA);
+        hB = __builtin_elementwise_fma(w2, (f2){v.z, v.w}, hB);
       }
-      ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2; ring[s][3] = h3;
+      ringA[s] = hA; ringB[s] = hB;
       if (ir >= 2 * SH) {                                  // wave-uniform (a scalar branch): the first 10 rows only fill the ring.  Rows ir - 10 .. ir are in the ring: output row y0 + ir - 10
-        float m1 = 0.f, m2 = 0.f, e = 0.f, q = 0.f;
+        f2 mA = {0.f, 0.f}, mB = {0.f, 0.f};              // (mu1, mu2), (E[x^2 + y^2], E[xy])
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
           const int r = (s + 1 + k) % 11;                  // oldest row first; the taps are symmetric
-          const float w = taps.w[k];
-          m1 = fmaf(w, ring[r][0], m1); m2 = fmaf(w, ring[r][1], m2); e = fmaf(w, ring[r][2], e); q = fmaf(w, ring[r][3], q);
+          const f2 w2 = {taps.w[k], taps.w[k]};
+          mA = __builtin_elementwise_fma(w2, ringA[r], mA);
+          mB = __builtin_elementwise_fma(w2, ringB[r], mB);
         }
+        const float m1 = mA.x, m2 = mA.y, e = mB.x, q = mB.y;
         const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
         const float num = (2.0f * m12 + C1) * (2.0f * (q - m12) + C2);
         const float den = (m11 + m22 + C1) * ((e - m11 - m22) + C2) + 1e-12f;
@@ -503,6 +523,12 @@ int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2,
   if (!ctx || !img1 || !img2 || !ssim_dev) return set_err(WM_ERR_BADARG, "NULL argument");
   WM_TRY(wmi::use_ctx(ctx));
   if (H <= 0 || W <= 0) return set_err(WM_ERR_BADARG, "H and W must be positive");
+  if (stride1 < (size_t)W || stride2 < (size_t)W) return set_err(WM_ERR_BADARG, "row stride < W");
+  {   // the kernel addresses each plane through a buffer resource with 32-bit offsets
+    const size_t e1 = (kind & 1) ? 4 : 1, e2 = (kind & 2) ? 4 : 1;
+    if (((size_t)(H - 1) * stride1 + W) * e1 >= ((size_t)1 << 31) || ((size_t)(H - 1) * stride2 + W) * e2 >= ((size_t)1 << 31))
+      return set_err(WM_ERR_BADARG, "SSIM planes must be smaller than 2 GiB");
+  }
   const dim3 grid((W + SS_W - 1) / SS_W, (H + SS_R - 1) / SS_R), block(64);
   const size_t nblk = (size_t)grid.x * grid.y;
   WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, (nblk + 1) * sizeof(double), "ssim partial sums"));
