@@ -256,13 +256,23 @@ struct GaussTaps { float w[11]; };
 #ifndef WM_SSIM_WAVES
 #define WM_SSIM_WAVES 4
 #endif
+#ifndef WM_SSIM_WPB
+#define WM_SSIM_WPB 1
+#endif
+constexpr int SS_WPB = WM_SSIM_WPB;       // independent waves per workgroup (each its own strip and LDS rows; no barrier)
 template <typename TA, typename TB, bool TINY>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVES, WM_SSIM_WAVES))) void k_ssim(const TA* __restrict__ img1, const size_t s1,
+__global__ __launch_bounds__(64 * SS_WPB) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVES, WM_SSIM_WAVES))) void k_ssim(const TA* __restrict__ img1, const size_t s1,
                                             const TB* __restrict__ img2, const size_t s2, const int H,
                                             const int W, const GaussTaps taps, double* __restrict__ out) {
-  __shared__ float4 rowbuf[2][2 * SS_W];                 // [0, 74): the row; lanes 10..63 park their (unused) halo value behind it: no branch
-  const int lane = threadIdx.x;
-  const int x0 = blockIdx.x * SS_W, y0 = blockIdx.y * SS_R;
+  __shared__ float4 rowbuf_all[SS_WPB][2][2 * SS_W];     // [0, 74): the row; lanes 10..63 park their (unused) halo value behind it: no branch
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float4 (*rowbuf)[2 * SS_W] = rowbuf_all[wv];
+  const int strip = blockIdx.x * SS_WPB + wv;
+  const int x0 = strip * SS_W, y0 = blockIdx.y * SS_R;
+  if (x0 >= W) {                                         // wave-uniform: a strip past the image contributes 0
+    if (lane == 0) out[(size_t)blockIdx.y * (gridDim.x * SS_WPB) + strip] = 0.0;
+    return;
+  }
   // source columns of this lane: main (x0 - 5 + lane) and, for lanes 0..9, the right halo (x0 + 59 + lane).
   // Columns / rows past the image (tile overhang) are clamped into range first: their outputs are masked out anyway.
   // Borders: one fold suffices unless the image is smaller than the halo (TINY: the general formula, its own instantiation
@@ -313,6 +323,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 ringA[11], ringB[11];
   float acc = 0.0f;
+#ifndef WM_SSIM_ROTPRIO
+#define WM_SSIM_ROTPRIO 4                                // rows per priority step; 0 = leave the priority alone
+#endif
+#if WM_SSIM_ROTPRIO
+  const int prio_rank = (int)(((unsigned)blockIdx.y * gridDim.x * SS_WPB + blockIdx.x * SS_WPB + wv) >> 10);   // dispatch order / 1 024 SIMDs
+#endif
   const float C1 = (0.01f * 255) * (0.01f * 255), C2 = (0.03f * 255) * (0.03f * 255);
   const bool col_ok = x0 + lane < W;
 #pragma unroll 1
@@ -320,6 +336,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
       const int ir = base + s;
+#if WM_SSIM_ROTPRIO
+      // the SIMD's arbiter prefers its OLDEST wave: the four waves of a SIMD finish one after the other (40 / 50 / 67 / 90
+      // thousand cycles, in-kernel stamps, profiles/r03y_ssim_stamps.log) and the youngest runs its last third alone,
+      // latency-bound.  A priority that rotates over the (dispatch-order) ranks every WM_SSIM_ROTPRIO rows shares the issue
+      // slots evenly: all four finish within 55-78 thousand cycles, 39.8 -> 37.2 us per 4K plane.
+      switch ((ir / WM_SSIM_ROTPRIO + prio_rank) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+#endif
       SSIM_FETCH((s + PF) % 11, ir + PF);                  // rows past n_in: clamped, never used
       float4* rb = rowbuf[ir & 1];                         // 11 is odd: the parity of s alone flips with base
       {
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WM_SSIM_WAVE
   double accd = (double)acc;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) accd += __shfl_down(accd, o, 64);
-  if (lane == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = accd;
+  if (lane == 0) out[(size_t)blockIdx.y * (gridDim.x * SS_WPB) + strip] = accd;
 }
 
 __global__ void k_sum_f64(const double* __restrict__ in, const size_t n, const double scale,
@@ -529,8 +557,8 @@ int wm_ssim_dev(wm_ctx* ctx, const void* img1, size_t stride1, const void* img2,
     if (((size_t)(H - 1) * stride1 + W) * e1 >= ((size_t)1 << 31) || ((size_t)(H - 1) * stride2 + W) * e2 >= ((size_t)1 << 31))
       return set_err(WM_ERR_BADARG, "SSIM planes must be smaller than 2 GiB");
   }
-  const dim3 grid((W + SS_W - 1) / SS_W, (H + SS_R - 1) / SS_R), block(64);
-  const size_t nblk = (size_t)grid.x * grid.y;
+  const dim3 grid(((W + SS_W - 1) / SS_W + SS_WPB - 1) / SS_WPB, (H + SS_R - 1) / SS_R), block(64 * SS_WPB);
+  const size_t nblk = (size_t)grid.x * SS_WPB * grid.y;
   WM_TRY(grow(ctx, &ctx->partials, &ctx->partials_bytes, (nblk + 1) * sizeof(double), "ssim partial sums"));
   double* part = (double*)ctx->partials;
   const GaussTaps taps = make_taps();
