@@ -506,6 +506,9 @@ def live_pmc_section(a, F, H, W, timeout_s=150):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None
+    # this process already runs under a profiler (rocprofv3 / rocprof preload its tool library): no nested profiling
+    if any(k.startswith(("ROCPROF", "ROCP_", "HSA_TOOLS_LIB")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     tmp = tempfile.mkdtemp(prefix="wm_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
