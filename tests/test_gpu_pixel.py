@@ -175,3 +175,35 @@ def test_one_call_extract_equals_the_three_step_chain(gpu_ctx):
         c.check_status()
         for d in (d_st, d_sc, d_u, d_v, d_ux, d_vx, d_w, d_a, d_b):
             c.free(d)
+
+
+def test_ssim_geometries_and_dtypes_against_the_oracle(gpu_ctx):
+    """k_ssim walks 64-column strips in bands of 34 rows with an 11-row register ring, reflect-101 borders, buffer-resource
+    addressing and a per-plane partial sum: sizes on, one short of and one past the strip / band / ring boundaries, planes
+    narrower than the halo, every uint8 / float32 combination of single:44-57's two arguments."""
+    rng = np.random.default_rng(23)
+    sizes = [(34, 64), (35, 65), (33, 63), (68, 128), (69, 129), (11, 11), (12, 10), (10, 12), (1, 40), (40, 1), (2, 2),
+             (45, 200), (101, 75), (136, 257)]
+    for (H, W) in sizes:
+        a = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        b = np.clip(a.astype(int) + rng.integers(-25, 26, a.shape), 0, 255).astype(np.uint8)
+        af = a.astype(np.float32) + rng.normal(0, 0.4, a.shape).astype(np.float32)
+        bf = b.astype(np.float32) + rng.normal(0, 0.4, b.shape).astype(np.float32)
+        for x, y in ((a, b), (a, bf), (af, b), (af, bf)):
+            got, want = gpu_ctx.ssim(x, y), o.ssim(x, y)
+            assert abs(got - want) < 3e-5, (H, W, x.dtype, y.dtype, got, want)
+    # the device entry point with a row stride larger than the width (a window of a larger plane)
+    H, W, S = 70, 100, 160
+    big1 = rng.integers(0, 256, (H, S), dtype=np.uint8); big2 = rng.integers(0, 256, (H, S), dtype=np.uint8)
+    d1 = gpu_ctx.malloc(big1.nbytes); d2 = gpu_ctx.malloc(big2.nbytes); ds = gpu_ctx.malloc(8)
+    try:
+        gpu_ctx.h2d(d1, big1); gpu_ctx.h2d(d2, big2)
+        from conftest import PKG_NAME
+        api = __import__("importlib").import_module(PKG_NAME + ".hostapi")
+        gpu_ctx._call("wm_ssim_dev", api._vp(d1), S, api._vp(d2), S, H, W, 0, api._vp(ds))
+        v = np.zeros(1); gpu_ctx.d2h(v, ds)
+        assert abs(float(v[0]) - o.ssim(big1[:, :W].copy(), big2[:, :W].copy())) < 3e-5
+        with pytest.raises(ValueError):
+            gpu_ctx._call("wm_ssim_dev", api._vp(d1), W - 1, api._vp(d2), S, H, W, 0, api._vp(ds))      # row stride < W
+    finally:
+        gpu_ctx.free(d1); gpu_ctx.free(d2); gpu_ctx.free(ds)
