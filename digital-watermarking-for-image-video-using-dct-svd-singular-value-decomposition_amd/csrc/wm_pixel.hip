@@ -231,14 +231,17 @@ __global__ __launch_bounds__(256) void k_sum_u64(const unsigned long long* __res
 // mean of  (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2))  with the 11 x 11, sigma 1.5 Gaussian moments.
 // s1 and s2 only enter as their SUM, so FOUR blurred fields suffice instead of the reference's five: x, y, x^2 + y^2, xy.
 //
-// Round 3 form (65-72 us per 4K plane -> see DESIGN 7.1): one wave per workgroup, one image COLUMN per lane, the wave
-// walks down SS_R output rows.  Per input row: the row's (x, y, x^2 + y^2, xy) of the wave's 74 columns go to LDS as one
-// float4 per pixel (two rows double-buffered: one barrier of a single wave per row), every lane reads its 11 neighbours
-// (ds_read_b128, conflict free) and forms the 4 horizontal sums - 44 FMAs whose tap is an SGPR operand - into a ring of
-// the last 11 rows held in REGISTERS (the row loop is unrolled 11 times, so the ring indices are static: no moves); the
-// vertical sums of the row that just became complete are 44 more FMAs, then the SSIM quotient.  Nothing is computed
-// twice except the horizontal sums of the 10 halo rows (SS_R = 34: 1.29 x on half of the arithmetic) and nothing but
-// the input row passes through LDS (the tiled form wrote and re-read five float planes of horizontal sums).
+// Form (72 -> 37 us per 4K plane over round 3): one wave per strip of 64 columns, one image COLUMN per
+// lane, the wave walks down SS_R output rows.  Per input row: the row's (x, y, x^2 + y^2, xy) of the wave's 74 columns go to
+// LDS as one float4 per pixel (two rows double-buffered; a single wave needs no barrier), every lane reads its 11
+// neighbours (ds_read_b128, conflict free) and forms the horizontal sums of the two field PAIRS - one v_pk_fma_f32 per pair
+// and tap, written as explicit 2-vectors - into a ring of the last 11 rows held in REGISTERS (the row loop is unrolled 11
+// times, so the ring indices are static: no moves); the vertical sums of the row that just became complete are 22 more
+// packed FMAs (skipped behind a wave-uniform branch while the ring fills), then the SSIM quotient.  Rows are addressed
+// through one buffer resource per image (lane column = VGPR offset, row = SGPR offset).  Nothing is computed twice except
+// the horizontal sums of the 10 halo rows (SS_R = 34: 1.29 x on half of the arithmetic) and nothing but the input row
+// passes through LDS.  What binds it (in-kernel stamps, occupancy sweep): a 725-cycle dependent chain per row that the
+// SIMD's oldest-first arbiter exposes in the youngest waves - hence the rotating priority below - then VALU issue.
 #ifndef WM_SSIM_ROWS
 #define WM_SSIM_ROWS 34
 #endif
