@@ -275,13 +275,18 @@ def _extract_arrays_fullframe(ctx, stego, meta, mode, alpha, kfrac, k_floor, H, 
             wy_s = _extract_plane_resized(ctx, Y, meta["Sc"], Uw, Vwt, alpha, kfrac, k_floor, H, W)
         return ctx.unpermute_normalize_u8(wy_s, idx, normalize)
     outs = []
+    # single:232-236: the three stego planes' singular values in ONE batched call (a single full-frame SVD is latency-bound on
+    # a fraction of the chip: 3 planes cost 1.4 x one, not 3 x), then single:248-264 per channel with its own factors
+    planes = np.ascontiguousarray(np.moveaxis(stego, -1, 0))
+    S_cw = ctx.ref_sigma_planes(planes)
     for ch, n in enumerate("bgr"):
-        U, Vt, Sc = meta["UW" + n], meta["VW" + n + "t"], meta["S" + n]
-        plane = np.ascontiguousarray(stego[..., ch])
-        if same:
-            w_s = ctx.ref_extract(plane, Sc, U, Vt, alpha, k_for(Sc, U.shape[0], Vt.shape[0]))
-        else:
-            w_s = _extract_plane_resized(ctx, plane, Sc, U, Vt, alpha, kfrac, k_floor, H, W)
+        U, Vt = meta["UW" + n], meta["VW" + n + "t"]
+        Sc = np.asarray(meta["S" + n], dtype=np.float32)
+        L = min(len(Sc), S_cw.shape[1], U.shape[0], Vt.shape[0])           # single:248
+        K = _k_of(L, kfrac, k_floor)                                       # single:249
+        sw_hat = ((S_cw[ch, :L] - Sc[:L]) / np.float32(max(alpha, 1e-8))).astype(np.float32)   # single:250-252
+        sw_hat[K:] = 0
+        w_s = ctx.ref_reconstruct(U, sw_hat, Vt, H, W)                     # single:257-264
         outs.append(ctx.unpermute_normalize_u8(w_s, idx, normalize))
     return np.stack(outs, axis=-1)
 
@@ -299,9 +304,13 @@ def detect_arrays(stego: np.ndarray, meta, thresh: float = 0.6, device: int = 0)
             score = (ctx.ref_detect(Y, meta["Sc"], meta["Sw"], alpha) if same                 # single:297-301
                      else _detect_plane_resized(ctx, Y, meta["Sc"], meta["Sw"], alpha))
             return bool(score >= thresh), float(score)
-        nc = [ctx.ref_detect(np.ascontiguousarray(stego[..., ch]), meta["S" + n], meta["SW" + n], alpha) if same
-              else _detect_plane_resized(ctx, np.ascontiguousarray(stego[..., ch]), meta["S" + n], meta["SW" + n], alpha)
-              for ch, n in enumerate("bgr")]                               # single:304-316
+        # single:304-316: the three planes' singular values in one batched call, the NC of each channel on the host
+        S_cw = ctx.ref_sigma_planes(np.ascontiguousarray(np.moveaxis(stego, -1, 0)))
+        nc = []
+        for ch, n in enumerate("bgr"):
+            Sc = np.asarray(meta["S" + n], dtype=np.float32).reshape(-1); Sw = np.asarray(meta["SW" + n], dtype=np.float32).reshape(-1)
+            L = min(len(Sc), S_cw.shape[1], len(Sw))                       # single:311-313
+            nc.append(_nc(Sw[:L], (S_cw[ch, :L] - Sc[:L]) / np.float32(max(alpha, 1e-8))))
         score = float((nc[0] + nc[1] + nc[2]) / 3.0)
         return bool(score >= thresh), score
     if mode == "gray":
