@@ -1495,93 +1495,107 @@ int wm_ref_embed_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint
 }
 
 // thin SVD of dct2(plane) (apply_dct != 0) or of the plane itself: U [H x L], S [L], Vt [L x W]
-int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* Vt, int H, int W,
-                   int row_stride, int apply_dct) {
-  WM_TRY(check_ref_args(ctx, plane, 1, H, W, row_stride, (size_t)H * row_stride));
+// Watermark-side SVD of n_planes planes (the B, G, R planes of a colour watermark, single:128-134) in ONE batch: a single
+// full-frame SVD is latency-bound on a fraction of the chip, three planes in every launch cost 1.4 x one.
+//   planes [n][H][row_stride..] float32 host, U [n][H][L], S [n][L], Vt [n][L][W] host
+int wm_ref_svd_planes_f32(wm_ctx* ctx, const float* planes, float* U, float* S, float* Vt, int n_planes, int H, int W,
+                          int row_stride, size_t plane_stride, int apply_dct) {
+  WM_TRY(check_ref_args(ctx, planes, n_planes, H, W, row_stride, plane_stride));
   if (!U || !S || !Vt) return set_err(WM_ERR_BADARG, "U/S/Vt is NULL");
-  const RefPlan p = make_plan(H, W);
+  const int B = n_planes;
+  const RefPlan p = make_plan(H, W, B);
   RefWs w;
-  const size_t n_in = (size_t)H * row_stride;
-  // tmp1: input plane, then sorted factor for download; tmp2: DCT intermediate, then T = A0 B^T [L][Lp]
-  WM_TRY(plan_workspace(ctx, p, w, std::max(n_in, (size_t)p.M * p.L) + (size_t)H * W, std::max((size_t)H * W, (size_t)p.L * p.Lp)));
+  const size_t n_in = span_of(B, H, W, row_stride, plane_stride);
+  const size_t n_in_a = (n_in + 63) & ~(size_t)63, hw = (size_t)H * W, fl = (size_t)p.M * p.L;
+  // tmp1: input planes | DCT planes [B][H][W] | one plane's sorted factor for download;  tmp2: DCT intermediate [B][H][W], then T = A0 B^T [B][L][Lp]
+  WM_TRY(plan_workspace(ctx, p, w, n_in_a + (size_t)B * hw + fl, std::max((size_t)B * hw, (size_t)B * p.L * p.Lp)));
   float* d_in = w.tmp1;
-  float* d_c = w.tmp1 + std::max(n_in, (size_t)p.M * p.L);     // H x W
-  WM_HIP(hipMemcpyAsync(d_in, plane, n_in * 4, hipMemcpyHostToDevice, ctx->stream));
-  const float* src = d_in; size_t src_stride = (size_t)row_stride;
+  float* d_c = d_in + n_in_a;            // [B][H][W]
+  float* d_f = d_c + (size_t)B * hw;     // [L][M] / [L][L]
+  WM_HIP(hipMemcpyAsync(d_in, planes, n_in * 4, hipMemcpyHostToDevice, ctx->stream));
+  const float* src = d_in; size_t src_stride = (size_t)row_stride, src_ps = plane_stride;
   if (apply_dct) {
     float *dH, *dW;
     WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
-    WM_TRY(sgemm(ctx, false, false, H, W, H, 1.0f, dH, H, d_in, row_stride, 0.0f, w.tmp2, W));   // D_H X
-    WM_TRY(sgemm(ctx, false, true, H, W, W, 1.0f, w.tmp2, W, dW, W, 0.0f, d_c, W));              // (D_H X) D_W^T
-    src = d_c; src_stride = (size_t)W;
+    WM_TRY(sgemm_b(ctx, false, false, H, W, H, 1.0f, dH, H, 0, d_in, row_stride, plane_stride, 0.0f, w.tmp2, W, hw, B));   // D_H X
+    WM_TRY(sgemm_b(ctx, false, true, H, W, W, 1.0f, w.tmp2, W, hw, dW, W, 0, 0.0f, d_c, W, hw, B));                      // (D_H X) D_W^T
+    src = d_c; src_stride = (size_t)W; src_ps = hw;
   }
-  hipLaunchKernelGGL((k_rf_load<float>), dim3(8, p.Lp, 1), dim3(256), 0, ctx->stream, src, src_stride, (size_t)0,
+  hipLaunchKernelGGL((k_rf_load<float>), dim3(8, p.Lp, B), dim3(256), 0, ctx->stream, src, src_stride, src_ps,
                      p.transpose ? 1 : 0, w.aug, p.aug_ps, p.ld, p.L, p.Lp, p.M);
   int sweeps = 0;
   WM_TRY(jacobi_rows(ctx, p, w, JR_SVD, &sweeps));
   if (sweeps < 0) return set_err(WM_ERR_NOCONV, "SVD did not converge");
-  std::vector<double> b2, q2; std::vector<int> order; std::vector<float> sig;
+  std::vector<double> b2, q2;
   WM_TRY(fetch_norms(ctx, p, w, true, b2, q2));
   // Singular values.  |b_i| / |q_i| is exact as long as B = Qt A holds, but the two parts of a row round
   // independently through ~1e5 MFMA row updates: measured 7e-5 relative low at 8K (3e-5 at 1080p), the same for
   // every value.  Like the sigma-only path (fetch_norms_t) the large values are therefore measured on the untouched
   // input, s_i = |A0 b_i^T| / |b_i| (error c^2 (s_max / s_i)^2 / 2 with the residual cosine c <= ref_skip_thr), and
   // the ratio of the two estimates there (median) calibrates |b_i| / |q_i| for the values below the switch.
-  std::vector<double> q2s = q2;                       // q2 itself still normalises the columns of the short-side factor
-  {
-    float* d_T = w.tmp2;
-    WM_TRY(sgemm(ctx, p.transpose, true, p.L, p.Lp, p.M, 1.0f, src, (int)src_stride, w.aug, p.ld, 0.0f, d_T, p.Lp));
-    hipLaunchKernelGGL(k_rf_colnorms, dim3((p.Lp + 63) / 64, 1), dim3(256), 0, ctx->stream, d_T, (size_t)0, p.L, p.Lp, w.q2);
-    WM_HIP(hipGetLastError());
-    std::vector<double> t2(p.Lp);
-    WM_HIP(hipMemcpyAsync(t2.data(), w.q2, t2.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(hipStreamSynchronize(ctx->stream));
+  float* d_T = w.tmp2;
+  WM_TRY(sgemm_b(ctx, p.transpose, true, p.L, p.Lp, p.M, 1.0f, src, (int)src_stride, src_ps, w.aug, p.ld, p.aug_ps, 0.0f, d_T, p.Lp,
+                 (size_t)p.L * p.Lp, B));
+  hipLaunchKernelGGL(k_rf_colnorms, dim3((p.Lp + 63) / 64, B), dim3(256), 0, ctx->stream, d_T, (size_t)p.L * p.Lp, p.L, p.Lp, w.q2);
+  WM_HIP(hipGetLastError());
+  std::vector<double> t2all((size_t)B * p.Lp);
+  WM_HIP(hipMemcpyAsync(t2all.data(), w.q2, t2all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WM_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<float> longf((size_t)p.L * p.M), shortf((size_t)p.L * p.L), sq(p.L), sb(p.L), sig;
+  std::vector<int> order;
+  for (int z = 0; z < B; ++z) {
+    const double* b2z = &b2[(size_t)z * p.Lp]; const double* q2z = &q2[(size_t)z * p.Lp]; const double* t2 = &t2all[(size_t)z * p.Lp];
+    std::vector<double> q2s(q2z, q2z + p.Lp);           // q2 itself still normalises the columns of the short-side factor
     double smax2 = 0.0;
-    for (int i = 0; i < p.Lp; ++i) if (q2[i] > 0.0) smax2 = std::max(smax2, b2[i] / q2[i]);
+    for (int i = 0; i < p.Lp; ++i) if (q2z[i] > 0.0) smax2 = std::max(smax2, b2z[i] / q2z[i]);
     const double ratio = T_SWITCH * (double)ctx->ref_skip_thr;
     std::vector<double> g;
     std::vector<unsigned char> above(p.Lp, 0);
     for (int i = 0; i < p.Lp; ++i) {
-      if (!(b2[i] > 0.0 && q2[i] > 0.0 && t2[i] > 0.0)) continue;
-      const double s2 = b2[i] / q2[i];
-      const double rho = sqrt(t2[i] * q2[i]) / b2[i];            // |T[:, i]| against |b_i| * (|b_i| / |q_i|)
-      if (fabs(rho - 1.0) < DRIFT_TOL && s2 >= ratio * ratio * smax2) { above[i] = 1; g.push_back(b2[i] * b2[i] / (q2[i] * t2[i])); }
+      if (!(b2z[i] > 0.0 && q2z[i] > 0.0 && t2[i] > 0.0)) continue;
+      const double s2 = b2z[i] / q2z[i];
+      const double rho = sqrt(t2[i] * q2z[i]) / b2z[i];            // |T[:, i]| against |b_i| * (|b_i| / |q_i|)
+      if (fabs(rho - 1.0) < DRIFT_TOL && s2 >= ratio * ratio * smax2) { above[i] = 1; g.push_back(b2z[i] * b2z[i] / (q2z[i] * t2[i])); }
     }
     double gcal = 1.0;
     if (g.size() >= 8) { std::sort(g.begin(), g.end()); gcal = g[g.size() / 2]; }
     for (int i = 0; i < p.Lp; ++i)
-      q2s[i] = above[i] ? b2[i] * b2[i] / t2[i] : q2[i] * gcal;
-  }
-  sort_sigma(p, b2.data(), q2s.data(), order, sig);
-  memcpy(S, sig.data(), (size_t)p.L * 4);
-  // short-side factor: columns q_i/|q_i|   (rows of Qt), long-side factor: rows b_i/|b_i|
-  std::vector<float> sq(p.L), sb(p.L);
-  for (int k = 0; k < p.L; ++k) {
-    const int i = order[k];
-    sq[k] = q2[i] > 0 ? (float)(1.0 / sqrt(q2[i])) : 0.0f;
-    sb[k] = b2[i] > 0 ? (float)(1.0 / sqrt(b2[i])) : 0.0f;
-  }
-  WM_HIP(hipMemcpyAsync(w.order, order.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
-  // long-side factor rows [L x M]
-  float* d_f = w.tmp1;
-  WM_HIP(hipMemcpyAsync(w.scale, sb.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, w.aug, p.ld, p.M, w.order, w.scale, d_f, p.M);
-  std::vector<float> longf((size_t)p.L * p.M), shortf((size_t)p.L * p.L);
-  WM_HIP(hipMemcpyAsync(longf.data(), d_f, longf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-  WM_HIP(hipStreamSynchronize(ctx->stream));
-  WM_HIP(hipMemcpyAsync(w.scale, sq.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, w.aug + p.M, p.ld, p.L, w.order, w.scale, d_f, p.L);
-  WM_HIP(hipMemcpyAsync(shortf.data(), d_f, shortf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-  WM_HIP(hipStreamSynchronize(ctx->stream));
-  // shortf[k][r] = k-th singular vector of the short side at coordinate r; longf[k][c] likewise
-  if (!p.transpose) {      // A = X: U[r][k] = shortf[k][r] (H x L), Vt[k][c] = longf[k][c] (L x W)
-    for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) U[(size_t)r * p.L + k] = shortf[(size_t)k * p.L + r];
-    memcpy(Vt, longf.data(), longf.size() * 4);
-  } else {                 // A = X^T: U[r][k] = longf[k][r] (H x L), Vt[k][c] = shortf[k][c] (L x W)
-    for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) U[(size_t)r * p.L + k] = longf[(size_t)k * p.M + r];
-    memcpy(Vt, shortf.data(), shortf.size() * 4);
+      q2s[i] = above[i] ? b2z[i] * b2z[i] / t2[i] : q2z[i] * gcal;
+    sort_sigma(p, b2z, q2s.data(), order, sig);
+    memcpy(S + (size_t)z * p.L, sig.data(), (size_t)p.L * 4);
+    // short-side factor: columns q_i/|q_i|   (rows of Qt), long-side factor: rows b_i/|b_i|
+    for (int k = 0; k < p.L; ++k) {
+      const int i = order[k];
+      sq[k] = q2z[i] > 0 ? (float)(1.0 / sqrt(q2z[i])) : 0.0f;
+      sb[k] = b2z[i] > 0 ? (float)(1.0 / sqrt(b2z[i])) : 0.0f;
+    }
+    const float* aug_z = w.aug + (size_t)z * p.aug_ps;
+    WM_HIP(hipMemcpyAsync(w.order, order.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
+    // long-side factor rows [L x M]
+    WM_HIP(hipMemcpyAsync(w.scale, sb.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, aug_z, p.ld, p.M, w.order, w.scale, d_f, p.M);
+    WM_HIP(hipMemcpyAsync(longf.data(), d_f, longf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    WM_HIP(hipMemcpyAsync(w.scale, sq.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, aug_z + p.M, p.ld, p.L, w.order, w.scale, d_f, p.L);
+    WM_HIP(hipMemcpyAsync(shortf.data(), d_f, shortf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    // shortf[k][r] = k-th singular vector of the short side at coordinate r; longf[k][c] likewise
+    float* Uz = U + (size_t)z * H * p.L; float* Vtz = Vt + (size_t)z * p.L * W;
+    if (!p.transpose) {      // A = X: U[r][k] = shortf[k][r] (H x L), Vt[k][c] = longf[k][c] (L x W)
+      for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) Uz[(size_t)r * p.L + k] = shortf[(size_t)k * p.L + r];
+      memcpy(Vtz, longf.data(), longf.size() * 4);
+    } else {                 // A = X^T: U[r][k] = longf[k][r] (H x L), Vt[k][c] = shortf[k][c] (L x W)
+      for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) Uz[(size_t)r * p.L + k] = longf[(size_t)k * p.M + r];
+      memcpy(Vtz, shortf.data(), shortf.size() * 4);
+    }
   }
   return WM_OK;
+}
+
+int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* Vt, int H, int W,
+                   int row_stride, int apply_dct) {
+  return wm_ref_svd_planes_f32(ctx, plane, U, S, Vt, 1, H, W, row_stride, (size_t)H * row_stride, apply_dct);
 }
 
 

@@ -137,11 +137,12 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
     if color:
         meta = dict(mode="color", **common)
         Sws = []
-        for ch, n in enumerate("bgr"):                                     # single:123-134
-            w_s = ctx.permute_planes(np.ascontiguousarray(wm[..., ch]), idx)
-            U, S, Vt = ctx.ref_svd(w_s, apply_dct=True)
-            meta["UW" + n] = U; meta["VW" + n + "t"] = Vt; meta["SW" + n] = S
-            Sws.append(S)
+        # single:123-134: the three scrambled watermark planes, their DCTs and SVDs as ONE batch
+        w_s = ctx.permute_planes(np.ascontiguousarray(np.moveaxis(wm, -1, 0)), idx)      # one shared permutation, single:124-126
+        Us, Ss, Vts = ctx.ref_svd_planes(w_s, apply_dct=True)
+        for ch, n in enumerate("bgr"):
+            meta["UW" + n] = np.ascontiguousarray(Us[ch]); meta["VW" + n + "t"] = np.ascontiguousarray(Vts[ch]); meta["SW" + n] = np.ascontiguousarray(Ss[ch])
+            Sws.append(meta["SW" + n])
         hosts = np.ascontiguousarray(np.moveaxis(cover, -1, 0))            # b, g, r planes, one batched call
         st, Sc, _ = ctx.ref_embed_planes(hosts, np.stack(Sws), alpha, K)   # single:127-147
         for ch, n in enumerate("bgr"):

@@ -83,6 +83,7 @@ SIGNATURES = {
     "wm_ref_extract_planes_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f, _i],
     "wm_ref_detect_planes_u8_dev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f],
     "wm_ref_svd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "wm_ref_svd_planes_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _i],
     "wm_ref_extract_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_extract_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _f, _i],
     "wm_ref_reconstruct_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i],
@@ -482,6 +483,19 @@ class Context:
         U = np.empty((H, L), np.float32); S = np.empty(L, np.float32); Vt = np.empty((L, W), np.float32)
         self._call("wm_ref_svd_f32", _vp(plane.ctypes.data), _vp(U.ctypes.data), _vp(S.ctypes.data),
                    _vp(Vt.ctypes.data), H, W, W, 1 if apply_dct else 0)
+        return U, S, Vt
+
+    def ref_svd_planes(self, planes: np.ndarray, apply_dct: bool = True):
+        """planes float32 [n, H, W] -> U [n, H, L], S [n, L], Vt [n, L, W]: the watermark-side SVDs of a colour watermark's
+        three planes (single:128-134) as one batch."""
+        if planes.dtype != np.float32 or planes.ndim != 3:
+            raise ValueError("planes must be float32 [n, H, W]")
+        planes = np.ascontiguousarray(planes)
+        n, H, W = planes.shape
+        L = min(H, W)
+        U = np.empty((n, H, L), np.float32); S = np.empty((n, L), np.float32); Vt = np.empty((n, L, W), np.float32)
+        self._call("wm_ref_svd_planes_f32", _vp(planes.ctypes.data), _vp(U.ctypes.data), _vp(S.ctypes.data),
+                   _vp(Vt.ctypes.data), n, H, W, W, H * W, 1 if apply_dct else 0)
         return U, S, Vt
 
     def ref_extract(self, stego: np.ndarray, sigma_c, Uw, Vwt, alpha: float, K: int) -> np.ndarray:

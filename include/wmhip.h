@@ -213,6 +213,12 @@ int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int
 int wm_ref_svd_f32(wm_ctx* ctx, const float* plane, float* U, float* S, float* Vt, int H, int W,
                    int row_stride, int apply_dct);
 
+/* The same for n_planes planes in ONE batch (the B, G, R planes of a colour watermark, single:128-134:
+ * `UWb, SWb, VWbt = svd(dct2(wb_s))` ... three times): every launch carries all planes.
+ *   planes [n][H][row_stride], U [n][H][L], S [n][L], Vt [n][L][W], host memory. */
+int wm_ref_svd_planes_f32(wm_ctx* ctx, const float* planes, float* U, float* S, float* Vt, int n_planes, int H, int W,
+                          int row_stride, size_t plane_stride, int apply_dct);
+
 /* Replaces single:205-218: sigma of the stego -> Sw_hat = (S_cw - Sc)/max(alpha,1e-8),
  * Sw_hat[K:] = 0 -> Uw[:L,:L] @ diag(Sw_hat) @ Vwt[:L,:L] zero-padded into H x W
  * (the reference's [:L,:L] truncation on non-square planes is reproduced) -> idct2.

@@ -389,3 +389,24 @@ def test_fullframe_random_scenes(gpu_ctx):
             ref = img.astype(np.float64) + (U[:, :K] * (alpha * Sw[:K].astype(np.float64))) @ Vt[:K]
             d = np.abs(np.clip(ref, 0, 255).astype(np.uint8).astype(int) - st.astype(int))
             assert d.max() <= 1 and np.mean(d != 0) < 5e-3, (case, int(d.max()))
+
+
+def test_batched_watermark_svd_equals_the_single_plane_calls(gpu_ctx):
+    """wm_ref_svd_planes_f32 (the three planes of a colour watermark in one batch, single:128-134) against three
+    wm_ref_svd_f32 calls and against float64 LAPACK: same singular values, factors that reproduce the DCT plane."""
+    rng = np.random.default_rng(31)
+    for (H, W) in ((64, 96), (96, 64), (72, 72)):
+        planes = rng.integers(0, 256, (3, H, W)).astype(np.float32)
+        planes[1] = np.sort(planes[1], axis=1)                     # a structured plane among the noise
+        Ub, Sb, Vb = gpu_ctx.ref_svd_planes(planes, apply_dct=True)
+        L = min(H, W)
+        assert Ub.shape == (3, H, L) and Sb.shape == (3, L) and Vb.shape == (3, L, W)
+        for z in range(3):
+            C = o.dct2(planes[z])
+            s64 = np.linalg.svd(C.astype(np.float64), compute_uv=False)
+            assert np.max(np.abs(Sb[z] - s64)) / s64[0] < 2e-6
+            U1, S1, V1 = gpu_ctx.ref_svd(planes[z], apply_dct=True)
+            assert np.max(np.abs(S1 - Sb[z])) / s64[0] < 2e-6
+            rec = (Ub[z] * Sb[z]) @ Vb[z]
+            assert np.max(np.abs(rec - C)) / s64[0] < 2e-5
+            assert np.max(np.abs(Ub[z].T @ Ub[z] - np.eye(L))) < 2e-4 and np.max(np.abs(Vb[z] @ Vb[z].T - np.eye(L))) < 2e-4
