@@ -77,6 +77,29 @@ def _check_tile(tile):
 # ---------------------------------------------------------------------------
 # array level (decoded images in, arrays out) - what the file level wraps
 # ---------------------------------------------------------------------------
+class _Later:
+    """A host-only computation (the HMAC over the meta's factors: 28 ms per 66 MB at 4K, the largest single item of a
+    tile-mode call) on a worker thread while this thread drives the device; hashlib and ctypes both release the GIL."""
+
+    def __init__(self, fn):
+        import threading
+        self._out = self._exc = None
+
+        def run():
+            try:
+                self._out = fn()
+            except BaseException as e:            # re-raised in result()
+                self._exc = e
+        self._t = threading.Thread(target=run, daemon=True)
+        self._t.start()
+
+    def result(self):
+        self._t.join()
+        if self._exc is not None:
+            raise self._exc
+        return self._out
+
+
 def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
                  alpha: float = 0.1, color: bool = False, kfrac: float = K_FRAC_DEFAULT,
                  tile: Optional[int] = TILE, k_floor: int = 8, device: int = 0) -> dict:
@@ -106,22 +129,24 @@ def embed_arrays(cover: np.ndarray, wm: np.ndarray, password: str, nonce: bytes,
         for ch, n in enumerate("bgr"):
             meta["S" + n] = Sc[ch]; meta["UW" + n] = U[ch]
             meta["VW" + n + "t"] = Vt[ch]; meta["SW" + n] = S[ch]
-        digest = hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"],
-                                      meta["UWb"], meta["UWg"], meta["UWr"],
-                                      meta["VWbt"], meta["VWgt"], meta["VWrt"]])   # single:152-156
-        meta["digest"] = np.frombuffer(digest, dtype=np.uint8)
-        return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
-                    ssim=ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego)))   # single:167
+        dg = _Later(lambda: hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"],
+                                                 meta["UWb"], meta["UWg"], meta["UWr"],
+                                                 meta["VWbt"], meta["VWgt"], meta["VWrt"]]))   # single:152-156, under the metrics below
+        ps = ctx.psnr(cover, stego)
+        ss = ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego))               # single:167
+        meta["digest"] = np.frombuffer(dg.result(), dtype=np.uint8)
+        return dict(stego=stego, meta=meta, psnr=ps, ssim=ss)
     Y = ctx.color("bgr2y", cover)                                          # single:169  (_to_Y)
     wy_s = ctx.permute_planes(ctx.color("bgr2gray", wm), idx)              # single:170-171 (index pass on the device)
     Uw, Sw, Vwt = ctx.svd_tiles(wy_s)                                      # single:173
     stegoY, Sc, Yw = ctx.embed_tiles(Y, Sw, alpha, K, want_yw=True)        # single:172-177
+    dg = _Later(lambda: hg.hmac_digest(key, [Sc, Uw, Vwt]))               # single:182, under the colour conversion and the metrics
     stego = ctx.color("replace_y", cover, stegoY)                          # single:26-30 (_from_Y)
-    digest = hg.hmac_digest(key, [Sc, Uw, Vwt])                            # single:182
+    ps = ctx.psnr(cover, stego)
+    ss = ctx.ssim(ctx.color("bgr2gray", cover), Yw)                        # single:190
     meta = dict(mode="gray", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw, **common,
-                digest=np.frombuffer(digest, dtype=np.uint8))              # single:183-189
-    return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
-                ssim=ctx.ssim(ctx.color("bgr2gray", cover), Yw))           # single:190
+                digest=np.frombuffer(dg.result(), dtype=np.uint8))         # single:183-189
+    return dict(stego=stego, meta=meta, psnr=ps, ssim=ss)
 
 
 def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac, k_floor) -> dict:
@@ -240,8 +265,22 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
     else:
         parts = [meta["S" + n] for n in "bgr"] + [meta["UW" + n] for n in "bgr"] \
             + [meta["VW" + n + "t"] for n in "bgr"]
-    if not hg.digests_equal(hg.hmac_digest(key, parts), digest):
+    # single:206-209,244-247: the HMAC check runs on a worker thread UNDER the device work (it is 28 ms per 66 MB of factors,
+    # more than everything else of a tile-mode extract); nothing is returned before it has passed, and a mismatch takes
+    # precedence over whatever else went wrong meanwhile, as in the reference, where it comes first
+    check = _Later(lambda: hg.digests_equal(hg.hmac_digest(key, parts), digest))
+    try:
+        out = _extract_checked(stego, meta, mode, alpha, kfrac, k_floor, H, W, key, normalize, device)
+    except BaseException:
+        if not check.result():
+            raise ValueError("Sai mật khẩu hoặc meta không khớp.") from None
+        raise
+    if not check.result():
         raise ValueError("Sai mật khẩu hoặc meta không khớp.")             # single:208-209,246-247
+    return out
+
+
+def _extract_checked(stego, meta, mode, alpha, kfrac, k_floor, H, W, key, normalize, device):
     tile = _meta_tile(meta)
     if tile is not None:
         _check_stego_shape(stego, meta)
