@@ -199,3 +199,24 @@ def test_device_index_cache_is_keyed_by_identity_not_address(hostapi):
     with pytest.raises(ValueError):
         ctx.index_dev(np.arange(16) + 1)
     ctx.__dict__["_h"] = None
+
+
+def test_extract_checks_the_hmac_before_anything_else_counts():
+    """The HMAC over the meta's factors runs on a worker thread under the device work; the reference checks it first
+    (single:206-209), so a mismatch must win over whatever else went wrong, and the other error must surface when the
+    password is right.  No device needed: a tile-mode meta for another stego size fails before any device call."""
+    import importlib
+    import dct_svd_core_secure as core
+    hg = importlib.import_module(core._impl.__package__ + ".hostglue")
+    rng = np.random.default_rng(3)
+    nonce = bytes(range(8))
+    Sc = rng.normal(0, 1, (2, 2, 8)).astype(np.float32)
+    Uw = rng.normal(0, 1, (2, 2, 8, 8)).astype(np.float32); Vwt = rng.normal(0, 1, (2, 2, 8, 8)).astype(np.float32)
+    digest = hg.hmac_digest(hg.derive_key("right", nonce), [Sc, Uw, Vwt])
+    meta = dict(mode="gray", alpha=0.1, shape=np.array((16, 16)), nonce=np.frombuffer(nonce, dtype=np.uint8),
+                digest=np.frombuffer(digest, dtype=np.uint8), Sc=Sc, Uw=Uw, Vwt=Vwt, tile=np.int32(8), kfrac=0.6)
+    stego_other_size = np.zeros((16, 24, 3), np.uint8)
+    with pytest.raises(ValueError, match="Sai mật khẩu"):
+        core.extract_arrays(stego_other_size, meta, "wrong")
+    with pytest.raises(ValueError, match="meta was written for"):
+        core.extract_arrays(stego_other_size, meta, "right")
