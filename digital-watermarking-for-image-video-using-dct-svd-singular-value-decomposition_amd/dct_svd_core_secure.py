@@ -387,7 +387,7 @@ def embed(cover_path: str, wm_source: str, out_path: str, meta_path: str,
         out_path = os.path.splitext(out_path)[0] + "_stego.png"            # single:148-149,178-179
     if not hg.write_png(out_path, r["stego"], 0):                          # single:150,180
         raise IOError("Ghi stego thất bại.")
-    (np.savez_compressed if compress_meta else np.savez)(meta_path, **r["meta"])   # single:157-166,183-189
+    hg.save_npz(meta_path, r["meta"], compressed=compress_meta)            # single:157-166,183-189 (np.savez_compressed; members deflated concurrently)
     return out_path, meta_path, r["psnr"], r["ssim"]
 
 
@@ -399,7 +399,7 @@ def extract(stego_path: str, meta_path: str, out_path: str, password: str,
     _check_password(password, "extract")
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để giải trích.")
-    data = np.load(meta_path, allow_pickle=False)                          # single:195
+    data = hg.load_npz(meta_path)                                          # single:195 (all members, inflated concurrently)
     st = hg.read_image_bgr(stego_path)                                     # single:201
     wm = extract_arrays(st, data, password, normalize, device)
     if enhance:

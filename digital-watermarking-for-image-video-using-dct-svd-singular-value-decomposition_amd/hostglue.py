@@ -10,6 +10,7 @@ include/wmhip.h.
 from __future__ import annotations
 
 import hashlib
+import time
 import os
 import hmac as _hmac
 import threading
@@ -219,6 +220,92 @@ def unpermute(plane: np.ndarray, idx: np.ndarray) -> np.ndarray:
     inv = np.empty_like(idx)
     inv[idx] = np.arange(idx.size)
     return plane.reshape(-1)[inv].reshape(H, W)
+
+
+def save_npz(path: str, arrays: dict, compressed: bool = True, threads: int = 32) -> str:
+    """``np.savez_compressed(path, **arrays)`` (single:157-166,183-189) with the members deflated CONCURRENTLY: the factors of
+    a tile-mode or colour meta are a handful of large float arrays, zlib releases the GIL, and a .npz is a plain zip - so
+    each member is serialised (the same .npy 1.0 header NumPy writes), deflated in chunks and CRC'd on worker threads and the
+    container is written by hand (stored sizes < 4 GiB; anything larger, or ``compressed=False``, goes through NumPy).
+    ``np.load`` - the reference's reader - sees an ordinary compressed .npz.  Returns the path written (NumPy's rule: '.npz' is
+    appended when missing)."""
+    import io
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    if not path.endswith(".npz"):
+        path = path + ".npz"
+    items = [(k, np.asanyarray(v)) for k, v in arrays.items()]
+    if not compressed or any(a.dtype.hasobject for _, a in items) or sum(a.nbytes for _, a in items) >= (1 << 31):
+        (np.savez_compressed if compressed else np.savez)(path, **arrays)
+        return path
+
+    # A member's deflate stream is cut into chunks of CHUNK bytes, each deflated on its own from a fresh state and closed
+    # with a sync flush (byte-aligned, not final) - the last one with Z_FINISH: concatenated they are ONE valid raw-deflate
+    # stream (pigz's construction), so even a single 33 MB factor spreads over the host's cores.
+    CHUNK = 1 << 22
+    heads, datas, jobs = [], [], []
+    for i, (name, a) in enumerate(items):
+        head = io.BytesIO()
+        np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(a))
+        heads.append(head.getvalue())
+        datas.append(np.ascontiguousarray(a).reshape(-1).view(np.uint8) if a.size else np.zeros(0, np.uint8))
+        n_chunks = max(1, -(-datas[i].size // CHUNK))
+        jobs += [(i, c, n_chunks) for c in range(n_chunks)]
+
+    def deflate(job):
+        i, c, n_chunks = job
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        out = co.compress(heads[i]) if c == 0 else b""
+        out += co.compress(datas[i][c * CHUNK:(c + 1) * CHUNK])
+        return out + (co.flush(zlib.Z_FINISH) if c == n_chunks - 1 else co.flush(zlib.Z_SYNC_FLUSH))
+
+    def crc(i):
+        return zlib.crc32(datas[i], zlib.crc32(heads[i])) & 0xFFFFFFFF
+
+    workers = max(1, min(threads, len(jobs) + len(items), (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        crcs = [ex.submit(crc, i) for i in range(len(items))]
+        parts = list(ex.map(deflate, jobs))
+    members = []
+    for i, (name, a) in enumerate(items):
+        comp = b"".join(p for (j, _, _), p in zip(jobs, parts) if j == i)
+        members.append(((name + ".npy").encode("utf-8"), comp, crcs[i].result(), len(heads[i]) + datas[i].size))
+    t = time.localtime()
+    dostime = (t.tm_hour << 11) | (t.tm_min << 5) | (t.tm_sec // 2)
+    dosdate = ((max(t.tm_year, 1980) - 1980) << 9) | (t.tm_mon << 5) | t.tm_mday
+    central = []
+    with open(path, "wb") as f:
+        for name, comp, crc, usize in members:
+            off = f.tell()
+            f.write(struct.pack("<IHHHHHIIIHH", 0x04034B50, 20, 0, 8, dostime, dosdate, crc, len(comp), usize, len(name), 0))
+            f.write(name); f.write(comp)
+            central.append(struct.pack("<IHHHHHHIIIHHHHHII", 0x02014B50, 20, 20, 0, 8, dostime, dosdate, crc, len(comp), usize,
+                                       len(name), 0, 0, 0, 0, 0o600 << 16, off) + name)
+        cd_off = f.tell()
+        for c in central:
+            f.write(c)
+        cd_size = f.tell() - cd_off
+        f.write(struct.pack("<IHHHHIIH", 0x06054B50, 0, 0, len(central), len(central), cd_size, cd_off, 0))
+    return path
+
+
+def load_npz(path: str, threads: int = 8) -> dict:
+    """Every member of a .npz (np.load(path, allow_pickle=False), single:195) read CONCURRENTLY into a dict: extract needs
+    all the factors, a colour meta holds six large ones, and inflating them one after the other was most of a file-level
+    extract (zlib releases the GIL; every worker opens its own handle).  KeyError / ValueError behaviour of the
+    members is NumPy's."""
+    from concurrent.futures import ThreadPoolExecutor
+    with np.load(path, allow_pickle=False) as z:
+        names = list(z.files)
+
+    def rd(k):
+        with np.load(path, allow_pickle=False) as z:
+            return k, z[k]
+    if len(names) <= 1:
+        return dict(rd(k) for k in names)
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(names)))) as ex:
+        return dict(ex.map(rd, names))
 
 
 def hmac_digest(key: bytes, arrays) -> bytes:

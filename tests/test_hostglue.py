@@ -134,3 +134,44 @@ def test_non_string_password_is_a_type_error_not_a_key():
         m.embed("cover.png", "wm.png", "out.png", "meta.npz", password="")
     with pytest.raises(ValueError):
         m.extract("stego.png", "meta.npz", "out.png", None)
+
+
+def test_save_npz_is_an_ordinary_compressed_npz(tmp_path):
+    """hostglue.save_npz writes what np.savez_compressed writes (single:157-166,183-189) - same member names, dtypes, shapes
+    and values for np.load, the reference's reader -, with the members deflated on worker threads; '.npz' is appended like
+    NumPy does; strings, 0-d and empty arrays included; uncompressed and oversized inputs go through NumPy itself."""
+    import zipfile
+    from conftest import PKG_NAME
+    hg = __import__("importlib").import_module(PKG_NAME + ".hostglue")
+    rng = np.random.default_rng(4)
+    meta = dict(mode="gray", payload_type="image", Sc=rng.normal(0, 1, (9, 7, 8)).astype(np.float32),
+                Uw=rng.normal(0, 1, (9, 7, 8, 8)).astype(np.float32), Vwt=rng.normal(0, 1, (9, 7, 8, 8)).astype(np.float32)[:, ::-1],
+                shape=np.array((72, 56)), alpha=0.12, kfrac=0.6, nonce=np.frombuffer(bytes(range(8)), dtype=np.uint8),
+                tile=np.int32(8), empty=np.zeros((0, 3), np.float32), big=rng.integers(0, 9, 300000).astype(np.int64))
+    p = hg.save_npz(str(tmp_path / "meta"), meta)
+    assert p.endswith("meta.npz") and zipfile.ZipFile(p).testzip() is None
+    np.savez_compressed(str(tmp_path / "ref.npz"), **meta)
+    a, b = np.load(p, allow_pickle=False), np.load(str(tmp_path / "ref.npz"), allow_pickle=False)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    assert all(i.compress_type == zipfile.ZIP_DEFLATED for i in zipfile.ZipFile(p).infolist())
+    q = hg.save_npz(str(tmp_path / "plain.npz"), meta, compressed=False)
+    c = np.load(q, allow_pickle=False)
+    assert all(np.array_equal(c[k], b[k]) for k in b.files)
+    assert all(i.compress_type == zipfile.ZIP_STORED for i in zipfile.ZipFile(q).infolist())
+
+
+def test_load_npz_reads_every_member(tmp_path):
+    from conftest import PKG_NAME
+    hg = __import__("importlib").import_module(PKG_NAME + ".hostglue")
+    rng = np.random.default_rng(6)
+    meta = dict(mode="color", Sb=rng.normal(0, 1, 40).astype(np.float32), UWb=rng.normal(0, 1, (64, 40)).astype(np.float32),
+                VWbt=rng.normal(0, 1, (40, 96)).astype(np.float32), alpha=0.2, nonce=np.frombuffer(bytes(8), dtype=np.uint8))
+    for comp in (True, False):
+        p = hg.save_npz(str(tmp_path / f"m{int(comp)}"), meta, compressed=comp)
+        d = hg.load_npz(p)
+        assert sorted(d) == sorted(meta) and str(d["mode"]) == "color" and float(d["alpha"]) == 0.2
+        assert all(np.array_equal(d[k], np.asarray(meta[k])) for k in meta)
+    with pytest.raises(FileNotFoundError):
+        hg.load_npz(str(tmp_path / "missing.npz"))
