@@ -38,14 +38,40 @@ def read_image_bgr(path: str) -> np.ndarray:
     return np.ascontiguousarray(rgb[..., ::-1])
 
 
+def _png_bytes(img: np.ndarray, compression: int) -> bytes:
+    """An 8-bit gray or RGB PNG written directly: scanlines with filter type 0, ONE zlib stream at the requested level
+    (level 0 - the reference's stego files - is stored blocks at memcpy speed), CRC per chunk.  Pillow's encoder took
+    60-100 ms for a 1080p stego at level 0 (it still walks the filter heuristics); this takes a tenth of that."""
+    import struct
+    import zlib
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else 3
+    raw = np.empty((h, 1 + w * ch), np.uint8)
+    raw[:, 0] = 0                                                   # filter type 0 (None) on every scanline
+    raw[:, 1:] = img.reshape(h, w * ch)
+    comp = zlib.compress(raw, int(min(max(compression, 0), 9)))
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(data, zlib.crc32(tag)) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 0 if ch == 1 else 2, 0, 0, 0)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", comp) + chunk(b"IEND", b"")
+
+
 def write_png(path: str, img: np.ndarray, compression: int = 0) -> bool:
-    """``cv2.imwrite(path, img, [IMWRITE_PNG_COMPRESSION, c])`` for BGR or gray uint8."""
+    """``cv2.imwrite(path, img, [IMWRITE_PNG_COMPRESSION, c])`` for BGR or gray uint8 (same pixels; the byte stream is this
+    module's own - filter type 0 throughout - where libpng picks filters per scanline)."""
     try:
-        if img.ndim == 2:
-            Image.fromarray(img, mode="L").save(path, format="PNG", compress_level=compression)
-        else:
-            Image.fromarray(np.ascontiguousarray(img[..., ::-1]), mode="RGB").save(
-                path, format="PNG", compress_level=compression)
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3) or img.size == 0 \
+                or img.shape[0] * (1 + img.shape[1] * (1 if img.ndim == 2 else 3)) >= (1 << 31):
+            if img.ndim == 2:                                       # anything unusual: Pillow's encoder
+                Image.fromarray(img, mode="L").save(path, format="PNG", compress_level=compression)
+            else:
+                Image.fromarray(np.ascontiguousarray(img[..., ::-1]), mode="RGB").save(path, format="PNG", compress_level=compression)
+            return True
+        data = _png_bytes(img if img.ndim == 2 else np.ascontiguousarray(img[..., ::-1]), compression)
+        with open(path, "wb") as f:
+            f.write(data)
         return True
     except Exception:
         return False

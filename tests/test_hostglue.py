@@ -175,3 +175,26 @@ def test_load_npz_reads_every_member(tmp_path):
         assert all(np.array_equal(d[k], np.asarray(meta[k])) for k in meta)
     with pytest.raises(FileNotFoundError):
         hg.load_npz(str(tmp_path / "missing.npz"))
+
+
+def test_write_png_round_trips_through_an_independent_decoder(tmp_path):
+    """hostglue.write_png builds the PNG itself (filter type 0, one zlib stream, level 0 = stored blocks like the reference's
+    stego files): Pillow - an independent decoder - must read back the same pixels for gray and BGR, odd sizes and every level."""
+    from PIL import Image
+    from conftest import PKG_NAME
+    hg = __import__("importlib").import_module(PKG_NAME + ".hostglue")
+    rng = np.random.default_rng(8)
+    for shape in ((1, 1), (7, 13), (64, 96), (33, 1), (5, 9, 3), (120, 67, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for level in (0, 1, 6):
+            p = str(tmp_path / f"a_{len(shape)}_{shape[0]}_{level}.png")
+            assert hg.write_png(p, img, level)
+            with Image.open(p) as im:
+                im.load()
+                got = np.asarray(im)
+                assert im.mode == ("L" if img.ndim == 2 else "RGB")
+            want = img if img.ndim == 2 else img[..., ::-1]
+            assert got.shape == want.shape and np.array_equal(got, want)
+            back = hg.read_image_bgr(p)
+            assert np.array_equal(back, img if img.ndim == 3 else np.repeat(img[..., None], 3, axis=2))
+    assert hg.write_png(str(tmp_path / "no_such_dir" / "x.png"), img, 0) is False
