@@ -266,10 +266,10 @@ def save_npz(path: str, arrays: dict, compressed: bool = True, threads: int = 32
         (np.savez_compressed if compressed else np.savez)(path, **arrays)
         return path
 
-    # A member's deflate stream is cut into chunks of CHUNK bytes, each deflated on its own from a fresh state and closed
+    # A member's deflate stream is cut into chunks of CHUNK bytes (1 MiB: 35 jobs for the factors of a 1080p tile-mode meta), each deflated on its own from a fresh state and closed
     # with a sync flush (byte-aligned, not final) - the last one with Z_FINISH: concatenated they are ONE valid raw-deflate
     # stream (pigz's construction), so even a single 33 MB factor spreads over the host's cores.
-    CHUNK = 1 << 22
+    CHUNK = 1 << 20
     heads, datas, jobs = [], [], []
     for i, (name, a) in enumerate(items):
         head = io.BytesIO()
