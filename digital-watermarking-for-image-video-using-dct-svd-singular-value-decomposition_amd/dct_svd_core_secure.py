@@ -399,8 +399,9 @@ def extract(stego_path: str, meta_path: str, out_path: str, password: str,
     _check_password(password, "extract")
     if not password:
         raise ValueError("Vui lòng nhập mật khẩu để giải trích.")
-    data = hg.load_npz(meta_path)                                          # single:195 (all members, inflated concurrently)
-    st = hg.read_image_bgr(stego_path)                                     # single:201
+    img = _Later(lambda: hg.read_image_bgr(stego_path))                    # single:201, decoded while the meta is read
+    data = hg.load_npz(meta_path)                                          # single:195 (all members, inflated concurrently); its errors come first, as in the reference
+    st = img.result()
     wm = extract_arrays(st, data, password, normalize, device)
     if enhance:
         wm = hg.unsharp(wm, 0.25 if wm.ndim == 2 else 0.15)               # single:95,109
