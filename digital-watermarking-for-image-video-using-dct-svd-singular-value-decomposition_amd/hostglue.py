@@ -38,6 +38,36 @@ def read_image_bgr(path: str) -> np.ndarray:
     return np.ascontiguousarray(rgb[..., ::-1])
 
 
+_DEFLATE_CHUNK = 1 << 20
+
+
+def _deflate_chunks(parts, level: int = 6, threads: int = 32):
+    """Raw-deflate streams of several byte buffers, every buffer cut into 1 MiB chunks that are deflated from a fresh state
+    on worker threads (zlib releases the GIL) and closed with a sync flush - byte-aligned, not final -, the last one with
+    Z_FINISH: concatenated, a buffer's chunks are ONE valid raw-deflate stream (pigz's construction).  parts: list of
+    (prefix bytes, uint8 array); returns the list of compressed streams in the same order."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = []
+    for i, (_, data) in enumerate(parts):
+        n_chunks = max(1, -(-data.size // _DEFLATE_CHUNK))
+        jobs += [(i, c, n_chunks) for c in range(n_chunks)]
+
+    def deflate(job):
+        i, c, n_chunks = job
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        out = co.compress(parts[i][0]) if c == 0 and parts[i][0] else b""
+        out += co.compress(parts[i][1][c * _DEFLATE_CHUNK:(c + 1) * _DEFLATE_CHUNK])
+        return out + (co.flush(zlib.Z_FINISH) if c == n_chunks - 1 else co.flush(zlib.Z_SYNC_FLUSH))
+
+    if len(jobs) == 1:
+        done = [deflate(jobs[0])]
+    else:
+        with ThreadPoolExecutor(max_workers=max(1, min(threads, len(jobs), os.cpu_count() or 1))) as ex:
+            done = list(ex.map(deflate, jobs))
+    return [b"".join(d for (j, _, _), d in zip(jobs, done) if j == i) for i in range(len(parts))]
+
+
 def _png_bytes(img: np.ndarray, compression: int) -> bytes:
     """An 8-bit gray or RGB PNG written directly: scanlines with filter type 0, ONE zlib stream at the requested level
     (level 0 - the reference's stego files - is stored blocks at memcpy speed), CRC per chunk.  Pillow's encoder took
@@ -49,7 +79,12 @@ def _png_bytes(img: np.ndarray, compression: int) -> bytes:
     raw = np.empty((h, 1 + w * ch), np.uint8)
     raw[:, 0] = 0                                                   # filter type 0 (None) on every scanline
     raw[:, 1:] = img.reshape(h, w * ch)
-    comp = zlib.compress(raw, int(min(max(compression, 0), 9)))
+    level = int(min(max(compression, 0), 9))
+    if level == 0 or raw.size <= _DEFLATE_CHUNK:
+        comp = zlib.compress(raw, level)
+    else:       # an extracted 1080p colour watermark is 6 MB of noise: 100 ms through one zlib.compress(level 1), a tenth in chunks
+        flat = raw.reshape(-1)
+        comp = b"\x78\x01" + _deflate_chunks([(b"", flat)], level)[0] + struct.pack(">I", zlib.adler32(flat) & 0xFFFFFFFF)
 
     def chunk(tag: bytes, data: bytes) -> bytes:
         return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(data, zlib.crc32(tag)) & 0xFFFFFFFF)
@@ -266,37 +301,18 @@ def save_npz(path: str, arrays: dict, compressed: bool = True, threads: int = 32
         (np.savez_compressed if compressed else np.savez)(path, **arrays)
         return path
 
-    # A member's deflate stream is cut into chunks of CHUNK bytes (1 MiB: 35 jobs for the factors of a 1080p tile-mode meta), each deflated on its own from a fresh state and closed
-    # with a sync flush (byte-aligned, not final) - the last one with Z_FINISH: concatenated they are ONE valid raw-deflate
-    # stream (pigz's construction), so even a single 33 MB factor spreads over the host's cores.
-    CHUNK = 1 << 20
-    heads, datas, jobs = [], [], []
-    for i, (name, a) in enumerate(items):
+    # every member's deflate stream in 1 MiB chunks on worker threads (_deflate_chunks), its CRC beside them
+    heads, datas = [], []
+    for name, a in items:
         head = io.BytesIO()
         np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(a))
         heads.append(head.getvalue())
         datas.append(np.ascontiguousarray(a).reshape(-1).view(np.uint8) if a.size else np.zeros(0, np.uint8))
-        n_chunks = max(1, -(-datas[i].size // CHUNK))
-        jobs += [(i, c, n_chunks) for c in range(n_chunks)]
-
-    def deflate(job):
-        i, c, n_chunks = job
-        co = zlib.compressobj(6, zlib.DEFLATED, -15)
-        out = co.compress(heads[i]) if c == 0 else b""
-        out += co.compress(datas[i][c * CHUNK:(c + 1) * CHUNK])
-        return out + (co.flush(zlib.Z_FINISH) if c == n_chunks - 1 else co.flush(zlib.Z_SYNC_FLUSH))
-
-    def crc(i):
-        return zlib.crc32(datas[i], zlib.crc32(heads[i])) & 0xFFFFFFFF
-
-    workers = max(1, min(threads, len(jobs) + len(items), (os.cpu_count() or 1)))
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        crcs = [ex.submit(crc, i) for i in range(len(items))]
-        parts = list(ex.map(deflate, jobs))
-    members = []
-    for i, (name, a) in enumerate(items):
-        comp = b"".join(p for (j, _, _), p in zip(jobs, parts) if j == i)
-        members.append(((name + ".npy").encode("utf-8"), comp, crcs[i].result(), len(heads[i]) + datas[i].size))
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(items)))) as ex:
+        crcs = [ex.submit(lambda i=i: zlib.crc32(datas[i], zlib.crc32(heads[i])) & 0xFFFFFFFF) for i in range(len(items))]
+        comps = _deflate_chunks(list(zip(heads, datas)), 6, threads)
+        members = [((name + ".npy").encode("utf-8"), comps[i], crcs[i].result(), len(heads[i]) + datas[i].size)
+                   for i, (name, _) in enumerate(items)]
     t = time.localtime()
     dostime = (t.tm_hour << 11) | (t.tm_min << 5) | (t.tm_sec // 2)
     dosdate = ((max(t.tm_year, 1980) - 1980) << 9) | (t.tm_mon << 5) | t.tm_mday

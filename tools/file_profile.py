@@ -4,6 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dct_svd_core_secure as core
 from PIL import Image
+COLOR = "--color" in sys.argv
 rng = np.random.default_rng(1)
 d = tempfile.mkdtemp()
 yy, xx = np.mgrid[0:1080, 0:1920]
@@ -11,9 +12,10 @@ cover = np.clip(128 + 70 * np.sin(xx / 37.0)[..., None] * np.cos(yy / 23.0)[...,
 Image.fromarray(cover).save(os.path.join(d, "cover.png"), compress_level=1)
 Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).save(os.path.join(d, "wm.png"))
 args = (os.path.join(d, "cover.png"), os.path.join(d, "wm.png"), os.path.join(d, "s.png"), os.path.join(d, "m.npz"))
-core.embed(*args, alpha=0.12, password="pw")
-pr = cProfile.Profile(); pr.enable()
-out, meta, ps, ss = core.embed(*args, alpha=0.12, password="pw")
+core.embed(*args, alpha=0.12, password="pw", color=COLOR)
+pr = cProfile.Profile()
+out, meta, ps, ss = core.embed(*args, alpha=0.12, password="pw", color=COLOR)
+pr.enable()
 core.extract(out, meta, os.path.join(d, "w.png"), password="pw")
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(16)
