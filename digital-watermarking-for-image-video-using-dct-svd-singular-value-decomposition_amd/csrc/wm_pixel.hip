@@ -326,6 +326,10 @@ __global__ __launch_bounds__(64 * SS_WPB) __attribute__((amdgpu_waves_per_eu(WM_
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 ringA[11], ringB[11];
   float acc = 0.0f;
+#ifdef WM_SSIM_STAMPS
+  unsigned long long st_e = 0, st_d = 0, t_mid = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef WM_SSIM_ROTPRIO
 #define WM_SSIM_ROTPRIO 4                                // rows per priority step; 0 = leave the priority alone
 #endif
@@ -339,6 +343,10 @@ __global__ __launch_bounds__(64 * SS_WPB) __attribute__((amdgpu_waves_per_eu(WM_
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
       const int ir = base + s;
+#ifdef WM_SSIM_STAMPS                                     // diagnostic build (tools/ssim_stamps_probe.py): s_memtime at the row top ...
+      const unsigned long long t_top = __builtin_amdgcn_s_memtime();
+      if (ir > 0) st_d += t_top - t_mid;
+#endif
 #if WM_SSIM_ROTPRIO
       // the SIMD's arbiter prefers its OLDEST wave: the four waves of a SIMD finish one after the other (40 / 50 / 67 / 90
       // thousand cycles, in-kernel stamps, profiles/r03y_ssim_stamps.log) and the youngest runs its last third alone,
@@ -375,6 +383,11 @@ __global__ __launch_bounds__(64 * SS_WPB) __attribute__((amdgpu_waves_per_eu(WM_
         hB = __builtin_elementwise_fma(w2, (f2){v.z, v.w}, hB);
       }
       ringA[s] = hA; ringB[s] = hB;
+#ifdef WM_SSIM_STAMPS                                     // ... and once the row's horizontal sums are in the ring
+      asm volatile("" :: "v"(hA), "v"(hB));
+      t_mid = __builtin_amdgcn_s_memtime();
+      st_e += t_mid - t_top;
+#endif
       if (ir >= 2 * SH) {                                  // wave-uniform (a scalar branch): the first 10 rows only fill the ring.  Rows ir - 10 .. ir are in the ring: output row y0 + ir - 10
         f2 mA = {0.f, 0.f}, mB = {0.f, 0.f};              // (mu1, mu2), (E[x^2 + y^2], E[xy])
 #pragma unroll
@@ -395,6 +408,11 @@ __global__ __launch_bounds__(64 * SS_WPB) __attribute__((amdgpu_waves_per_eu(WM_
     }
   }
 #undef SSIM_FETCH
+#ifdef WM_SSIM_STAMPS
+  if (lane == 0 && (blockIdx.x % 12 == 5) && (blockIdx.y % 9 == 4))      // a sample of workgroups across the dispatch order
+    printf("blk %2d %2d rank %d dur %llu E %llu D %llu\n", blockIdx.x, blockIdx.y, (int)(((unsigned)blockIdx.y * gridDim.x + blockIdx.x) >> 10),
+           (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin), st_e / n_in, st_d / n_in);
+#endif
   double accd = (double)acc;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) accd += __shfl_down(accd, o, 64);

@@ -1,3 +1,6 @@
+"""k_ssim with in-kernel s_memtime stamps (a -DWM_SSIM_STAMPS build: `tools/build_variants.sh stamps:"-DWM_SSIM_STAMPS"`, add
+`-DWM_SSIM_ROTPRIO=0` for the arbiter's own oldest-first order): per sampled workgroup its dispatch rank, lifetime and the
+cycles per row up to the ring write (E) and from there to the next row (D).  Output: the kernel's printf lines."""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, "/root/repo")
