@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256) void k_sum_u64(const unsigned long long* __res
 // packed FMAs (skipped behind a wave-uniform branch while the ring fills), then the SSIM quotient.  Rows are addressed
 // through one buffer resource per image (lane column = VGPR offset, row = SGPR offset).  Nothing is computed twice except
 // the horizontal sums of the 10 halo rows (SS_R = 34: 1.29 x on half of the arithmetic) and nothing but the input row
-// passes through LDS.  What binds it (in-kernel stamps, occupancy sweep): a 725-cycle dependent chain per row that the
-// SIMD's oldest-first arbiter exposes in the youngest waves - hence the rotating priority below - then VALU issue.
+// passes through LDS.  What binds it (in-kernel stamps, occupancy sweep, ablations): VALU issue - 77 instructions per row of
+// which 48 are the packed FMAs - at about 80 % of the SIMD's cycles; a lone wave needs 725 cycles per row (a dependent chain).
 #ifndef WM_SSIM_ROWS
 #define WM_SSIM_ROWS 34
 #endif
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * SS_WPB) __attribute__((amdgpu_waves_per_eu(WM_
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
 #ifndef WM_SSIM_ROTPRIO
-#define WM_SSIM_ROTPRIO 4                                // rows per priority step; 0 = leave the priority alone
+#define WM_SSIM_ROTPRIO 0                                // rows per priority step; 0 (default) = leave the priority alone
 #endif
 #if WM_SSIM_ROTPRIO
   const int prio_rank = (int)(((unsigned)blockIdx.y * gridDim.x * SS_WPB + blockIdx.x * SS_WPB + wv) >> 10);   // dispatch order / 1 024 SIMDs
@@ -348,11 +348,15 @@ __global__ __launch_bounds__(64 * SS_WPB) __attribute__((amdgpu_waves_per_eu(WM_
       if (ir > 0) st_d += t_top - t_mid;
 #endif
 #if WM_SSIM_ROTPRIO
-      // the SIMD's arbiter prefers its OLDEST wave: the four waves of a SIMD finish one after the other (40 / 50 / 67 / 90
-      // thousand cycles, in-kernel stamps, profiles/r03y_ssim_stamps.log) and the youngest runs its last third alone,
-      // latency-bound.  A priority that rotates over the (dispatch-order) ranks every WM_SSIM_ROTPRIO rows shares the issue
-      // slots evenly: all four finish within 55-78 thousand cycles, 39.8 -> 37.2 us per 4K plane.
+      // Diagnostic option (-DWM_SSIM_ROTPRIO=n).  The SIMD's arbiter prefers its OLDEST wave: the four waves of a
+      // SIMD finish one after the other (40 / 50 / 67 / 90 thousand cycles, in-kernel stamps, profiles/r03y_ssim_stamps.log).
+      // A priority that rotates over the dispatch-order ranks every n rows makes them finish together (55-78 thousand) - and
+      // changes nothing in the kernel's time (five boxes, interleaved A/B): the SIMD is VALU-issue-bound either way.
+#ifdef WM_SSIM_STATICPRIO
+      switch (prio_rank & 3) {
+#else
       switch ((ir / WM_SSIM_ROTPRIO + prio_rank) & 3) {
+#endif
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
