@@ -24,8 +24,53 @@ K_FRAC_DEFAULT = 0.6  # single:13
 
 
 # ---- image I/O  (single:15-19, 150, 180, 228, 280) --------------------------
+def _read_png_unfiltered(path: str):
+    """Fast path for the PNGs this module writes itself (8-bit gray / RGB, not interlaced, every scanline with filter type
+    0): inflate and reshape - no per-pixel unfiltering, a 4K stego in 15 ms instead of 60.  Anything else (other colour
+    types, bit depths, interlacing, a palette, any filtered scanline, a damaged stream) returns None and goes to Pillow."""
+    import struct
+    import zlib
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:8] != b"\x89PNG\r\n\x1a\n":
+            return None
+        pos, idat, ihdr = 8, [], None
+        while pos + 8 <= len(data):
+            (n,), tag = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+            body = data[pos + 8:pos + 8 + n]
+            if tag == b"IHDR":
+                ihdr = struct.unpack(">IIBBBBB", body)
+            elif tag == b"IDAT":
+                idat.append(body)
+            elif tag == b"IEND":
+                break
+            elif tag in (b"PLTE", b"tRNS") or not (tag[0] & 0x20):      # palette / transparency, or a critical chunk this reader does not know
+                return None
+            pos += 12 + n
+        if ihdr is None or not idat:
+            return None
+        w, h, depth, ctype, _, _, interlace = ihdr
+        if depth != 8 or ctype not in (0, 2) or interlace != 0 or w == 0 or h == 0:
+            return None
+        ch = 1 if ctype == 0 else 3
+        raw = zlib.decompress(b"".join(idat))
+        if len(raw) != h * (1 + w * ch):
+            return None
+        a = np.frombuffer(raw, np.uint8).reshape(h, 1 + w * ch)
+        if a[:, 0].any():
+            return None
+        px = a[:, 1:].reshape(h, w, ch)
+        return np.ascontiguousarray(px[..., ::-1]) if ch == 3 else np.repeat(px, 3, axis=2)
+    except Exception:
+        return None
+
+
 def read_image_bgr(path: str) -> np.ndarray:
     """``cv2.imread(path, cv2.IMREAD_COLOR)``: always 3-channel BGR uint8."""
+    fast = _read_png_unfiltered(path) if str(path).lower().endswith(".png") else None
+    if fast is not None:
+        return fast
     try:
         with Image.open(path) as im:
             if im.mode in ("I;16", "I;16L", "I;16B", "I"):         # 16-bit gray: OpenCV keeps the high byte

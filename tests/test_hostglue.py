@@ -198,3 +198,29 @@ def test_write_png_round_trips_through_an_independent_decoder(tmp_path):
             back = hg.read_image_bgr(p)
             assert np.array_equal(back, img if img.ndim == 3 else np.repeat(img[..., None], 3, axis=2))
     assert hg.write_png(str(tmp_path / "no_such_dir" / "x.png"), img, 0) is False
+
+
+def test_read_image_fast_path_equals_pillow(tmp_path):
+    """read_image_bgr takes PNGs whose scanlines all carry filter type 0 (what write_png produces) without Pillow; every
+    other PNG - filtered scanlines, palette, 16-bit, interlaced, RGBA - must come out exactly as Pillow decodes it."""
+    from PIL import Image
+    from conftest import PKG_NAME
+    hg = __import__("importlib").import_module(PKG_NAME + ".hostglue")
+    rng = np.random.default_rng(12)
+    yy, xx = np.mgrid[0:70, 0:90]
+    smooth = np.clip(100 + 60 * np.sin(xx / 9.0) + yy, 0, 255).astype(np.uint8)
+    bgr = np.stack([smooth, smooth[::-1], rng.integers(0, 256, smooth.shape, dtype=np.uint8)], axis=-1)
+    own = str(tmp_path / "own.png"); assert hg.write_png(own, bgr, 0)
+    assert hg._read_png_unfiltered(own) is not None and np.array_equal(hg.read_image_bgr(own), bgr)
+    own_g = str(tmp_path / "own_g.png"); assert hg.write_png(own_g, smooth, 1)
+    assert np.array_equal(hg.read_image_bgr(own_g), np.repeat(smooth[..., None], 3, axis=2))
+    pil = str(tmp_path / "pil.png"); Image.fromarray(bgr[..., ::-1].copy()).save(pil, compress_level=6)      # adaptive filters
+    assert np.array_equal(hg.read_image_bgr(pil), bgr)
+    pal = str(tmp_path / "pal.png"); Image.fromarray(smooth).convert("P").save(pal)
+    want = np.asarray(Image.open(pal).convert("RGB"))[..., ::-1]
+    assert hg._read_png_unfiltered(pal) is None and np.array_equal(hg.read_image_bgr(pal), want)
+    rgba = str(tmp_path / "rgba.png"); Image.fromarray(np.dstack([bgr[..., ::-1], smooth])).save(rgba)
+    assert hg._read_png_unfiltered(rgba) is None and np.array_equal(hg.read_image_bgr(rgba), bgr)
+    inter = str(tmp_path / "bad.png"); open(inter, "wb").write(open(own, "rb").read()[:200])                  # truncated file
+    with pytest.raises(ValueError, match="Không mở được ảnh"):
+        hg.read_image_bgr(inter)
