@@ -914,11 +914,13 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
   std::vector<unsigned> bits(p.B);
   static const int full_sweeps = getenv("WM_RF_FULL_SWEEPS") ? atoi(getenv("WM_RF_FULL_SWEEPS")) : FULL_INNER_SWEEPS;
   // number of plane groups (HIP queues): WM_RF_QUEUES=n (1..4), WM_RF_ONE_QUEUE=1 is the old spelling of n = 1
-  static const int max_queues = [] {
+  // default: two groups, three from 12 planes on (16 planes: 131 -> 137 frames/s on two boxes, 24: 138 -> 139; 8 planes: 107 / 106)
+  static const int env_queues = [] {
     if (getenv("WM_RF_ONE_QUEUE") && atoi(getenv("WM_RF_ONE_QUEUE"))) return 1;
-    const int n = getenv("WM_RF_QUEUES") ? atoi(getenv("WM_RF_QUEUES")) : DEFAULT_QUEUES;
-    return n < 1 ? 1 : (n > 1 + wm_ctx::MAX_AUX ? 1 + wm_ctx::MAX_AUX : n);
+    const int n = getenv("WM_RF_QUEUES") ? atoi(getenv("WM_RF_QUEUES")) : 0;
+    return n < 1 ? 0 : (n > 1 + wm_ctx::MAX_AUX ? 1 + wm_ctx::MAX_AUX : n);
   }();
+  const int max_queues = env_queues ? env_queues : std::min(1 + wm_ctx::MAX_AUX, p.B >= 12 ? DEFAULT_QUEUES + 1 : DEFAULT_QUEUES);
   static const float conv_sigma = getenv("WM_RF_CONV_SIGMA") ? (float)atof(getenv("WM_RF_CONV_SIGMA")) : CONV_COS_SIGMA;
   // The accumulated factor of JR_SVD needs every rotation; the other two uses stop earlier: a residual
   // cosine c moves the stego by c * s_max / s_i of a (sub-LSB) term and the singular values by the
