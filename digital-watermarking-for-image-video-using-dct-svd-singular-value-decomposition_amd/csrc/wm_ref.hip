@@ -771,8 +771,10 @@ RefPlan make_plan(int H, int W, int B = 1) {
   // Work per workgroup grows with the batch: with many planes in a launch the grid is large anyway,
   // so a workgroup takes more columns (R / partial-sum traffic amortised, loads pipelined); a single
   // plane keeps the small units that fill the chip.
-  const int units = p.npairs * B;                       // (pair, plane) items per step
-  p.apply_tiles = units >= 96 ? 2 : 1;
+  // (round 2 gave a workgroup two 32-column blocks per wave from 96 (pair, plane) items per step on; with the batch split
+  // into two or three plane groups a launch rarely gets there, and one block per wave measures the same or better at every
+  // batch size: 8 planes 106.8 / 106.4, 16 planes 139.3 / 137.2, 24 planes 140.4 / 139.4 frames/s - profiles/r03z_fullframe_queues.log)
+  p.apply_tiles = 1;
   if (const char* e = getenv("WM_RF_APPLY_TILES")) { const int v = atoi(e); if (v >= 1 && v <= 8) p.apply_tiles = v; }   // tuning knob
   p.nch = (p.M + GRAM_CC - 1) / GRAM_CC;    // Gram stays in many small units: a float4 / double-buffered / 512-column variant measured slower (36-40 vs 31 us)
   return p;
