@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=32, help="frames per rank per step")
+    ap.add_argument("--frames", type=int, default=64,
+                    help="frames per rank per step (64 since round 3b: a launch of 32 frames is 21 rounds of resident waves and "
+                         "loses 5 %% to its last one - 19.9 k frames/s at 32, 20.9 k at 64, 20.7 k at 128 / 256, profiles/r03z_frames_sweep.log)")
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--alpha", type=float, default=0.15)
