@@ -52,11 +52,17 @@ struct wm_ctx {
   void* pair_tab[MAX_PAIR_TABS] = {};
   int pair_tab_nbk[MAX_PAIR_TABS] = {};
   int pair_tab_next = 0;
+  void* hier_dev[MAX_PAIR_TABS] = {};       // two-level (super-block) tournament tables of the block Jacobi, by block count: device part
+  void* hier_host[MAX_PAIR_TABS] = {};      // ... and the host part (malloc)
+  int hier_key[MAX_PAIR_TABS] = {};         // block count * 16 + super-block size the table was built for
+  int hier_next = 0;
+  void* hier_ws = nullptr;        // grow-only workspace of the two-level scheme (tracked Gram matrices, rotations, partial sums)
+  size_t hier_ws_bytes = 0;
   float* dct_mat[2] = {nullptr, nullptr};   // cached DCT-II basis matrices (device), by size
   int dct_n[2] = {0, 0};
   int ref_last_sweeps = 0;        // outer Jacobi sweeps of the last full-frame SVD (diagnostics)
   float ref_skip_thr = 0.0f;      // residual cosine the last full-frame Jacobi may have left between two rows
-  static constexpr int MAX_AUX = 3;   // extra queues of the batched full-frame Jacobi (created on first use)
+  static constexpr int MAX_AUX = 7;   // extra queues of the batched full-frame Jacobi (created on first use)
   hipStream_t aux_stream[MAX_AUX] = {};
   hipEvent_t ev_fork[MAX_AUX] = {}, ev_join[MAX_AUX] = {};
   hipEvent_t ev[wmi::N_EVENTS] = {};
@@ -74,6 +80,8 @@ inline int use_ctx(const wm_ctx* ctx) {
 }
 // grow-only device buffer (synchronises the stream before freeing the old one)
 int grow(wm_ctx* ctx, void** buf, size_t* have, size_t bytes, const char* what);
+// wm_ref.hip: releases the host part of a two-level tournament table (wm_ctx::hier_host)
+void hier_host_free(void* tab);
 // wm_route.hip: routed unscramble + normalise; mm_ext != NULL: n_part_ext {min, max} pairs per plane already on the device
 // (order-preserving uint form), include_zero: the value 0 also takes part in the min / max
 int route_unpermute_normalize(wm_ctx* ctx, const float* src, const wm_route* r, uint8_t* dst, size_t n, int n_planes, int do_norm,

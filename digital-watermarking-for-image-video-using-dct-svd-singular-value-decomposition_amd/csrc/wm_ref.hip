@@ -21,7 +21,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
+#include <new>
 #include <numeric>
+#include <utility>
 #include <vector>
 
 #include "wm_internal.h"
@@ -261,6 +264,12 @@ __device__ __forceinline__ int rr_elem(const int pos, const int step) {
 // that nothing else can run under.  256 threads (one wave per SIMD) lose the latency hiding (39.7 us per
 // solve against 30.1); 512 threads issue the per-pair angle and index arithmetic half as often as 1024 and
 // are 14 % faster on an 8-plane batch (98 against 86 frames/s), equal on a single plane.
+// Two-level (super-block) scheme, see "hierarchical block Jacobi" further down: a super-pair is at most HSB
+// 32-row blocks (HN rows); its Gram matrix G_s and accumulated rotation Q_s are HN x HN arrays (pitch HN) in
+// global memory, and a stage rotates HU disjoint block pairs ("units") of it.
+constexpr int HSB = 12;
+constexpr int HN = HSB * RB;
+constexpr int HU = HSB / 2;
 #ifndef WM_INNER_NT
 #define WM_INNER_NT 512
 #endif
@@ -272,7 +281,12 @@ constexpr int INNER_NB = 32 / INNER_KR;        // 2x2 blocks of G per thread
 __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__ partials, const int nch,
                                                       float* __restrict__ Rout, unsigned* __restrict__ maxcos_bits,
                                                       const float* __restrict__ floor2, const int cross_only,
-                                                      int* __restrict__ skip_flags, const float skip_thr) {
+                                                      int* __restrict__ skip_flags, const float skip_thr,
+                                                      const int* __restrict__ h_units, float* __restrict__ h_Gs,
+                                                      int* __restrict__ h_anyrot, const int h_nsp) {
+  // h_units != NULL: two-level scheme.  blockIdx.x = super-pair * HU + unit; the unit's two 32-row blocks (local
+  // indices la, lb of the super-pair) are read straight out of the tracked Gram matrix G_s (no partial sums), and
+  // the rotated 64 x 64 matrix R^T G R is written back into G_s at the end.
   __shared__ float GG[2][RP][RP + 1];   // double-buffered: a step reads one copy, writes the other
   float (*G)[RP + 1] = GG[0];
   __shared__ float R[RP][RP + 1];
@@ -287,6 +301,14 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   // rows whose squared norm is below this plane's floor are numerically null (rounding residue of
   // a rank-deficient plane): their mutual cosines are O(1) noise and must not hold convergence up
   const float fl2 = floor2[blockIdx.z];
+  int la = 0, lb = 0;
+  float* gs = nullptr;
+  if (h_units) {
+    const int unit = h_units[p];
+    if (unit < 0 || !((unit >> 16) & 1)) return;   // no such unit in this super-pair at this stage / an idle pair
+    la = unit & 0xff; lb = (unit >> 8) & 0xff;
+    gs = h_Gs + ((size_t)blockIdx.z * h_nsp + p / HU) * HN * HN;
+  }
   const float* src = partials + (size_t)p * nch * GRAM_PART;
   // Sum of the column-chunk partials, as 16-byte loads with up to 16 chunks (128 VGPRs) in flight per thread: the
   // workgroup is alone on its CU and this phase is one CU's fetch rate (profiles/r02_fullframe_inner.md).
@@ -298,7 +320,19 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   float4 acc[PER4];
 #pragma unroll
   for (int i = 0; i < PER4; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  {
+  if (h_units) {
+    for (int f = t; f < RP * RP / 4; f += INNER_NT) {
+      const int r = f >> 4, c4 = (f & 15) * 4;
+      const int gr = (r < RB) ? la * RB + r : lb * RB + r - RB;
+      const int gc = (c4 < RB) ? la * RB + c4 : lb * RB + c4 - RB;
+      const float4 v = *reinterpret_cast<const float4*>(gs + (size_t)gr * HN + gc);
+      G[r][c4] = v.x; G[r][c4 + 1] = v.y; G[r][c4 + 2] = v.z; G[r][c4 + 3] = v.w;
+      if (!cross_only) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R[r][c4 + k] = (r == c4 + k) ? 1.0f : 0.0f;
+      }
+    }
+  } else {
     const float4* src4 = reinterpret_cast<const float4*>(src);
     for (int ch = 0; ch < nch; ch += UN) {
       float4 v[UN][PER4];
@@ -342,6 +376,15 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #endif
   // largest cosine between two rows of the pair, from the sums still in registers and the diagonal in LDS
   float mx = 0.0f;
+  if (h_units) {
+    for (int f = t; f < RP * RP; f += INNER_NT) {
+      const int r = f >> 6, c = f & 63;
+      if (r < c) {
+        const float grr = G[r][r], gcc = G[c][c];
+        if (grr > fl2 && gcc > fl2) mx = fmaxf(mx, fabsf(G[r][c]) * __builtin_amdgcn_rsqf(grr * gcc));
+      }
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < PER4; ++i) {
     const int f = t + INNER_NT * i;
@@ -355,6 +398,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
         if (r != c + k && grr > fl2 && gcc > fl2) mx = fmaxf(mx, fabsf(av[k]) * __builtin_amdgcn_rsqf(grr * gcc));
       }
     }
+  }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
@@ -374,6 +418,17 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   }
   __syncthreads();
   if (s_skip) return;
+  if (h_units && t == 0) h_anyrot[(size_t)blockIdx.z * h_nsp + p / HU] = 1;     // this super-pair's rows do get rotated
+  // two-level scheme: the rotated Gram matrix (pitch RP + 1 in LDS) goes back into G_s
+  auto writeback = [&](const float* gf) {
+    for (int f = t; f < RP * RP / 4; f += INNER_NT) {
+      const int r = f >> 4, c4 = (f & 15) * 4;
+      const int gr = (r < RB) ? la * RB + r : lb * RB + r - RB;
+      const int gc = (c4 < RB) ? la * RB + c4 : lb * RB + c4 - RB;
+      const float* q = gf + r * (RP + 1) + c4;
+      *reinterpret_cast<float4*>(gs + (size_t)gr * HN + gc) = make_float4(q[0], q[1], q[2], q[3]);
+    }
+  };
 
   // Every lane computes the rotation of pair (lane & 31) - the wave's two halves redundantly - so the
   // rotation of the thread's COLUMN pair k2 is in its own registers, and those of its ROW pairs
@@ -503,6 +558,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
       out[r * RP + k2] = ri[j];
       out[r * RP + RB + k2] = rj[j];
     }
+    if (h_units) writeback(gbuf0);             // 32 steps: the result is back in buffer 0, behind the last step's barrier
 #if defined(WM_INNER_DIAG)
     __syncthreads();
     if (t == 0 && p == 1 && blockIdx.z == 0) {
@@ -581,6 +637,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   st3 = __builtin_amdgcn_s_memtime();
 #endif
   for (int e = t; e < RP * RP; e += INNER_NT) out[e] = R[e >> 6][e & 63];
+  if (h_units) writeback(&G[0][0]);
 #if defined(WM_INNER_DIAG)
   __syncthreads();
   if (t == 0 && p == 1 && blockIdx.z == 0) {
@@ -895,6 +952,8 @@ int get_dct_pair(wm_ctx* ctx, int H, int W, float** dH, float** dW) {
   return WM_OK;
 }
 
+#include "wm_ref_hier.inc"
+
 // block one-sided Jacobi on the B Aug matrices (already loaded); every launch covers
 // a group of planes (grid.z), sweeps continue until every plane's Gram matrices are
 // diagonal to CONV_COS.  sweeps_out: sweeps used (negative: bound hit).
@@ -967,17 +1026,72 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
                          w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1, w.skip + (size_t)z0 * p.npairs,
-                         skip_thr);
+                         skip_thr, (const int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
       const int n_blk = (ncols + 31) / 32, per_wg = 4 * p.apply_tiles;     // 32-column blocks, 4 waves per workgroup
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_blk + per_wg - 1) / per_wg, nz), dim3(256), 0, st,
                          aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R, w.skip + (size_t)z0 * p.npairs);
     }
+  };
+  // Two-level scheme (wm_ref_hier.inc): the same rotations with the rows streamed 3 times per SUPER-step.
+  // WM_RF_HIER=0 selects the flat tournament (read per call, so that a test can hold the two against each other);
+  // WM_RF_HIER_SB = blocks per super-block (2, 4 or 6).
+  const bool hier = !(getenv("WM_RF_HIER") && atoi(getenv("WM_RF_HIER")) == 0);
+  const HierTab* ht = nullptr;
+  HierWs hw{};
+  const int hdbg = getenv("WM_RF_HDBG") ? atoi(getenv("WM_RF_HDBG")) : 0;     // timing experiments only (results are wrong): see the kernels
+  if (hier) {
+    int sb = 6;
+    if (const char* e = getenv("WM_RF_HIER_SB")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 6) sb = v; }
+    WM_TRY(get_hier(ctx, p.nbk, sb, &ht));
+    WM_TRY(plan_hier_ws(ctx, p, *ht, (p.B + NQ - 1) / NQ, hw));
+    static bool attr_set = false;
+    if (!attr_set) {
+      WM_HIP(hipFuncSetAttribute((const void*)k_happly, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HN * 33 * 4));
+      attr_set = true;
+    }
+  }
+  auto hstep = [&](hipStream_t st, int g, int s1) {
+    const int z0 = zb[g], nz = zb[g + 1] - zb[g], nsp = ht->nsp;
+    const HSuper* sup = ht->d_super + (size_t)s1 * nsp;
+    float* aug = w.aug + (size_t)z0 * p.aug_ps;
+    float* Gs = hw.Gs + (size_t)z0 * nsp * HN * HN;
+    float* Qs = hw.Qs + (size_t)z0 * nsp * HN * HN;
+    float* R = hw.R + (size_t)z0 * nsp * HU * RP * RP;
+    float* par = hw.partials + (size_t)z0 * nsp * HG_TILES * hw.KS * HG_T * HG_T;
+    int* skip = hw.skip + (size_t)z0 * nsp * HU;
+    int* anyrot = hw.anyrot + (size_t)z0 * nsp;
+    const int n32 = ht->nmax * RB, ntiles = n32 <= HG_T ? 1 : n32 <= 2 * HG_T ? 3 : HG_TILES;
+    const int nchunk = (p.M + HG_KC - 1) / HG_KC;
+    const int KS = hier_ks(nsp, nz, ntiles, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
+    const int ngrp = nsp * KS * nz;               // (super-pair, split, plane) groups of ntiles workgroups, dealt over the XCDs
+    hipLaunchKernelGGL(k_hgram, dim3(((ngrp + 7) / 8) * 8 * ntiles), dim3(256), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
+                       par, KS, cps, ntiles, nz, hdbg);
+    hipLaunchKernelGGL(k_hreduce, dim3(HSB * (HSB + 1) / 2, nsp, nz), dim3(256), 0, st, par, sup, nsp, KS, Gs, Qs, anyrot);
+    constexpr int NG = HU * (HU - 1) / 2;
+    for (int t = 0; t < ht->T[s1]; ++t) {
+      const int* un = ht->d_units + (size_t)(ht->stage_off[s1] + t) * nsp * HU;
+      hipLaunchKernelGGL(k_rf_inner, dim3(nsp * HU, 1, nz), dim3(INNER_NT), 0, st, (const float*)nullptr, 0, R, w.maxcos + z0,
+                         w.floor2 + z0, (s1 == 0 && t == 0) ? 0 : 1, skip, skip_thr, un, Gs, anyrot, nsp);
+      const bool last = t + 1 == ht->T[s1];        // nothing reads G_s after the last stage: only Q_s <- Q_s P
+      hipLaunchKernelGGL(k_hupdate, dim3(last ? HU * HU : NG + HU * HU, nsp, nz), dim3(256), 0, st, un, sup, nsp, R, skip, Gs, Qs,
+                         last ? NG : 0);
+    }
+    hipLaunchKernelGGL(k_happly, dim3(ctx->n_cu), dim3(64 * ht->nmax), (size_t)2 * n32 * 33 * 4, st, aug, p.aug_ps, p.ld, ncols, sup, nsp,
+                       nz, Qs, anyrot, n32, hdbg >> 4);
   };
   while (!done && sweep < MAX_SWEEPS) {
     WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));
     // group g starts one gram after group g - 1, so that the groups' latency-bound inner solves
     // fall under each other's gram / apply tiles instead of all at the same time
     auto q = [&](int g) { return g == 0 ? ctx->stream : ctx->aux_stream[g - 1]; };
+    if (hier) {
+      for (int g = 1; g < NQ; ++g) {               // the other queues start behind the memset
+        if (g == 1) WM_HIP(hipEventRecord(ctx->ev_fork[0], ctx->stream));
+        WM_HIP(hipStreamWaitEvent(q(g), ctx->ev_fork[0], 0));
+      }
+      for (int s1 = 0; s1 < ht->nsteps1; ++s1)
+        for (int g = 0; g < NQ; ++g) hstep(q(g), g, s1);
+    } else {
     for (int g = 0; g < NQ; ++g) {
       if (g > 0) WM_HIP(hipStreamWaitEvent(q(g), ctx->ev_fork[g - 1], 0));
       step(q(g), g, 0, 1);
@@ -986,6 +1100,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     for (int g = 0; g < NQ; ++g) step(q(g), g, 0, 2);
     for (int s = 1; s < p.nsteps; ++s)
       for (int g = 0; g < NQ; ++g) step(q(g), g, s, 3);
+    }
     for (int g = 1; g < NQ; ++g) {
       WM_HIP(hipEventRecord(ctx->ev_join[g - 1], q(g)));
       WM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g - 1], 0));
@@ -1363,6 +1478,10 @@ int fetch_f32(wm_ctx* ctx, const float* d, size_t n, std::vector<float>& h) {
 }
 
 }  // namespace
+
+namespace wmi {
+void hier_host_free(void* tab) { delete static_cast<HierTab*>(tab); }
+}
 
 // ===========================================================================
 // C ABI (see include/wmhip.h)

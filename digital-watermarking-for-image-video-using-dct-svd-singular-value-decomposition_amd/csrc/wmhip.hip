@@ -13,6 +13,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o libwmhip.so wmhip.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 
@@ -1001,6 +1002,11 @@ int wm_destroy(wm_ctx* ctx) {
   if (ctx->route_tmp) (void)hipFree(ctx->route_tmp);
   if (ctx->extract_f32) (void)hipFree(ctx->extract_f32);
   for (int i = 0; i < wm_ctx::MAX_PAIR_TABS; ++i) if (ctx->pair_tab[i]) (void)hipFree(ctx->pair_tab[i]);
+  for (int i = 0; i < wm_ctx::MAX_PAIR_TABS; ++i) {
+    if (ctx->hier_dev[i]) (void)hipFree(ctx->hier_dev[i]);
+    if (ctx->hier_host[i]) wmi::hier_host_free(ctx->hier_host[i]);
+  }
+  if (ctx->hier_ws) (void)hipFree(ctx->hier_ws);
   for (int i = 0; i < 2; ++i) if (ctx->dct_mat[i]) (void)hipFree(ctx->dct_mat[i]);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
