@@ -50,7 +50,10 @@ def parse():
     ap.add_argument("--mode", choices=("tile", "fullframe"), default="tile",
                     help="tile: the 8x8 hot path (contract default); fullframe: the reference's own "
                          "semantics (one dense SVD per plane), secondary workload")
-    ap.add_argument("--ff-frames", type=int, default=16, help="full-frame section: planes per rank per step")
+    ap.add_argument("--ff-frames", type=int, default=48,
+                    help="full-frame section: planes per rank per step (rounds 3: 16; from 20 planes per call on the library runs the "
+                         "two-level block Jacobi, which keeps gaining up to ~48: 139 / 158 / 169 / 178 frames/s at 16 / 24 / 32 / 48 - "
+                         "the 16-plane figure is still reported as value_at_16_planes)")
     ap.add_argument("--ff-height", type=int, default=1080)
     ap.add_argument("--ff-width", type=int, default=1920)
     ap.add_argument("--no-fullframe", action="store_true", help="skip the full-frame section of the default line")
@@ -412,27 +415,46 @@ def fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup,
     if rank != 0:
         return None
     Lp = (L + 63) // 64 * 64; M = max(H, W); nbk = Lp // 32
-    # GEMM tiles of one sweep: the Gram kernel computes three of the four 32 x 32 quadrants (G is symmetric), the apply all of R^T X
-    flops_sweep = (nbk - 1) * (nbk // 2) * (2.0 * 3 * 32 * 32 * M + 2.0 * 64 * 64 * M)
-    achieved = flops_sweep * sweeps_e * F / t_embed / 1e12
+    # matrix-core flops the embed's block Jacobi issued, as the library counted them at launch (pairs skipped as converged
+    # included): flat tournament = three 32 x 32 Gram quadrants + the 64 x 64 rotation per pair and step; two-level scheme =
+    # 128 x 128 Gram tiles + one (<= 384)^2 rotation per super-pair and super-step + the stage updates
+    flops_issued, two_level = ctx.ref_last_flops()
+    achieved = flops_issued / t_embed / 1e12
     # SURVEY 8(d)'s algorithmic count of what the embed computes per plane: one thin SVD, 6 M N^2 + 20 N^3 (M long, N short side)
     alg_flops = F * (6.0 * M * L * L + 20.0 * float(L) ** 3)
     achieved_alg = alg_flops / t_embed / 1e12
+    # the same workload at round 3's batch (16 planes per step: the flat tournament), for continuity
+    v16 = None
+    if F != 16 and world == 1 and not os.environ.get("WM_BENCH_NO_V16"):
+        f16, s16, c16, w16 = frames[:16].contiguous(), stego[:16].contiguous(), sc[:16].contiguous(), wm_out[:16].contiguous()
+        def step16():
+            ctx.ref_embed_planes_u8_dev(f16.data_ptr(), Sw.data_ptr(), s16.data_ptr(), c16.data_ptr(), None, 16, H, W, W, H * W, 0, alpha, K)
+            ctx.ref_extract_planes_u8_dev(s16.data_ptr(), c16.data_ptr(), Uw.data_ptr(), Vwt.data_ptr(), w16.data_ptr(), 16, H, W, W, H * W, alpha, K)
+        if F >= 16:
+            step16(); torch.cuda.synchronize(dev)
+            t16 = time.perf_counter()
+            for _ in range(2):
+                step16()
+            torch.cuda.synchronize(dev)
+            v16 = 2 * 16 / (time.perf_counter() - t16)
     out = {"metric": "frames/sec embed+extract, full-frame (reference semantics) Y plane",
            "value": world * F * steps / dt, "unit": "frames/s", "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "dtype": "f32",
            "workload": f"full-frame (tile=None) embed+extract, {F} planes/rank/step of {W}x{H} uint8 Y, alpha={alpha}, K={K}, "
                        f"device-resident (wm_ref_*_dev)",
+           "planes_per_step": F, "value_at_16_planes": v16, "two_level_block_jacobi": two_level,
            "embed_ms": t_embed * 1e3, "embed_ms_per_plane": t_embed * 1e3 / F,
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                         "achieved_algorithmic": achieved_alg, "frac_algorithmic": achieved_alg / MFMA_F32_PEAK_TFLOPS,
                         "algorithmic_flops_per_launch": alg_flops,
-                        "kernel": "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)",
-                        "note": f"{sweeps_e} sweeps x {nbk - 1} steps; `achieved` / `frac` count the Jacobi's OWN issued gram (3 quadrants) + "
-                                f"apply flops over the whole embed call (the per-pair inner solve and the finalisation GEMMs are in "
-                                f"the time, not in the flops); `frac_algorithmic` prices the same time against SURVEY 8(d)'s thin-SVD "
-                                f"count 6MN^2 + 20N^3 per plane - the figure to compare implementations by"}}
+                        "kernel": ("two-level block Jacobi (k_hgram + k_happly + k_hupdate products)" if two_level else
+                                   "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)"),
+                        "note": f"{sweeps_e} sweeps over {nbk} blocks of 32 rows; `achieved` / `frac` count the Jacobi's OWN issued matrix-core "
+                                f"flops (wm_ref_last_flops) over the whole embed call (the per-pair inner solve and the finalisation GEMMs "
+                                f"are in the time, not in the flops); `frac_algorithmic` prices the same time against SURVEY 8(d)'s thin-SVD "
+                                f"count 6MN^2 + 20N^3 per plane - the figure to compare implementations by; `traffic`: profiles/ "
+                                f"(FETCH_SIZE x 2 + WRITE_SIZE per launch of each Jacobi kernel)"}}
     if cpu_sample:
         from oracle import wm_oracle as o
         f0 = frames[0].cpu().numpy()
@@ -480,7 +502,7 @@ def main_fullframe(a):
                "config": {"workload": r["workload"], "frames_per_rank": a.ff_frames, "height": a.ff_height,
                           "width": a.ff_width, "parallelism": f"frames sharded over {world} rank(s)"},
                "roofline": r["roofline"], "embed_ms_per_plane": r["embed_ms_per_plane"]}
-        for k in ("cpu_baseline", "parity"):
+        for k in ("cpu_baseline", "parity", "planes_per_step", "value_at_16_planes", "two_level_block_jacobi"):
             if k in r:
                 out[k] = r[k]
         print(json.dumps(out), flush=True)
@@ -556,6 +578,74 @@ def live_pmc_section(a, F, H, W, timeout_s=150):
                 "traffic_source": "measured in this run: child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes "
                                   "(one each) of `bench.py --quick` at this shape, per k_embed_tiles launch; FETCH_SIZE x 1024 x 2 "
                                   "(gfx950 correction, an upper bound for our 4-8 B/lane reads) + WRITE_SIZE x 1024"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_pmc_fullframe(a, timeout_s=240):
+    """HBM traffic of the full-frame block Jacobi measured IN THIS RUN: two child `rocprofv3 --kernel-trace --pmc` passes
+    (FETCH_SIZE, then WRITE_SIZE) round `bench.py --mode fullframe --steps 1` of the same shape; per SVD call =
+    sum over the Jacobi kernels' dispatches / number of SVD calls (one k_rf_load<unsigned char> each).  KiB units and the
+    x2 gfx950 FETCH_SIZE correction as MI355X_MICROARCH.md prescribes.  Anything that goes wrong returns None."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "HSA_TOOLS_LIB")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    csv.field_size_limit(1 << 30)
+    tmp = tempfile.mkdtemp(prefix="wm_pmcff_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", WM_BENCH_NO_V16="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    jac = ("k_rf_gram", "k_rf_inner", "k_rf_apply", "k_hgram", "k_hreduce", "k_hupdate", "k_hpack", "k_happly")
+    tot, per_kernel, calls = {}, {}, 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "fullframe", "--steps", "1", "--cpu-frames", "0",
+                   "--ff-frames", str(a.ff_frames), "--ff-height", str(a.ff_height), "--ff-width", str(a.ff_width), "--alpha", str(a.alpha)]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return None
+            if rc != 0:
+                return None
+            acc, n_load = 0.0, 0
+            for f in glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    if "k_rf_load<unsigned char>" in name and r["Counter_Name"] == counter:
+                        n_load += 1
+                    for k in jac:
+                        if k + "(" in name or k + "<" in name:
+                            v = float(r["Counter_Value"]) * 1024
+                            acc += v
+                            per_kernel.setdefault(k, {}).setdefault(counter, 0.0)
+                            per_kernel[k][counter] += v
+                            break
+            if not n_load or not acc:
+                return None
+            tot[counter] = acc / n_load
+            calls = n_load
+            shutil.rmtree(os.path.join(tmp, counter), ignore_errors=True)
+        fetch_b, write_b = 2.0 * tot["FETCH_SIZE"], tot["WRITE_SIZE"]
+        return {"traffic": fetch_b + write_b, "fetch_bytes_x2_corrected": fetch_b, "write_bytes": write_b, "svd_calls_profiled": calls,
+                "per_kernel_bytes_per_svd_call": {k: {"fetch_x2": 2.0 * v.get("FETCH_SIZE", 0.0) / calls, "write": v.get("WRITE_SIZE", 0.0) / calls}
+                                                  for k, v in per_kernel.items()},
+                "traffic_source": "measured in this run: child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of "
+                                  "`bench.py --mode fullframe --steps 1` at this shape; bytes of the block-Jacobi kernels (k_rf_* / k_h*) per "
+                                  "SVD call of `planes_per_step` planes; FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024"}
     except Exception:
         return None
     finally:
@@ -765,6 +855,14 @@ def main():
             # full-frame semantics on BASELINE config 2's shape, with its own roofline and CPU baseline
             out["fullframe"] = fullframe_section(a, torch, dist, api, dev, rank, world, ctx, 2, 1,
                                                  cpu_sample=a.cpu_frames > 0)
+            if not a.no_live_pmc:
+                torch.cuda.synchronize(dev)
+                live_ff = live_pmc_fullframe(a)
+                if live_ff:
+                    rf = out["fullframe"]["roofline"]
+                    rf["traffic"] = live_ff["traffic"]
+                    rf["traffic_detail"] = {k: v for k, v in live_ff.items() if k != "traffic"}
+                    rf["traffic_over_plane_bytes"] = live_ff["traffic"] / (a.ff_frames * 4.0 * a.ff_height * a.ff_width)
         if world == 1 and not a.quick:
             hg = importlib.import_module(PKG + ".hostglue")
             idx = hg.permutation_index(H, W, hg.derive_key("bench", bytes(8)))       # single:62-69, host (NumPy PCG64)

@@ -61,6 +61,8 @@ struct wm_ctx {
   float* dct_mat[2] = {nullptr, nullptr};   // cached DCT-II basis matrices (device), by size
   int dct_n[2] = {0, 0};
   int ref_last_sweeps = 0;        // outer Jacobi sweeps of the last full-frame SVD (diagnostics)
+  double ref_last_flops = 0.0;    // matrix-core flops its Gram / rotation products issued (nominal: skipped pairs counted)
+  int ref_last_hier = 0;          // 1: it ran the two-level scheme
   float ref_skip_thr = 0.0f;      // residual cosine the last full-frame Jacobi may have left between two rows
   static constexpr int MAX_AUX = 7;   // extra queues of the batched full-frame Jacobi (created on first use)
   hipStream_t aux_stream[MAX_AUX] = {};

@@ -48,6 +48,7 @@ constexpr float CONV_COS_SIGMA = 2e-4f;
 constexpr float SKIP_FRACTION = 0.25f;    // a block pair below this fraction of the (embed) stopping cosine is left alone
 constexpr double RESIDUE_RHO = 10.0;      // |A0 b_i^T| / |b_i|^2 above this: b_i is not a singular direction at all
 constexpr double T_SWITCH = 200.0;        // |A0 b_i^T| / |b_i| is used for s_i >= T_SWITCH * (residual cosine) * s_max
+constexpr int HIER_MIN_PLANES = 20;        // planes per call from which the two-level scheme (wm_ref_hier.inc) is the default
 constexpr int DEFAULT_QUEUES = 2;         // plane groups of a batched Jacobi, each on its own HIP queue
 constexpr double DRIFT_TOL = 1e-2;        // |T[:, i]| / |b_i|^2 may differ from 1 by the scale drift, not more
 constexpr double NULL_ROW_RATIO = 1e-5;   // rows below this fraction of |A|_F do not take part in the convergence test
@@ -1033,9 +1034,12 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     }
   };
   // Two-level scheme (wm_ref_hier.inc): the same rotations with the rows streamed 3 times per SUPER-step.
-  // WM_RF_HIER=0 selects the flat tournament (read per call, so that a test can hold the two against each other);
+  // WM_RF_HIER=0 / 1 forces the flat tournament / the two-level scheme (read per call, so that a test can hold the two against each other);
   // WM_RF_HIER_SB = blocks per super-block (2, 4 or 6).
-  const bool hier = !(getenv("WM_RF_HIER") && atoi(getenv("WM_RF_HIER")) == 0);
+  // Default: from HIER_MIN_PLANES planes per call on (measured crossover on 1080p planes, profiles/r04_hier_crossover.log: 20 planes
+  // 144 / 144 frames/s, 24: 141 / 158, 48: 142 / 178 flat / two-level; a small batch is latency-bound and the flat step's chain
+  // gram - inner - apply is the shorter one: 2 planes 20.9 / 26.5 ms).
+  const bool hier = getenv("WM_RF_HIER") ? atoi(getenv("WM_RF_HIER")) != 0 : p.B >= HIER_MIN_PLANES;
   const HierTab* ht = nullptr;
   HierWs hw{};
   const int hdbg = getenv("WM_RF_HDBG") ? atoi(getenv("WM_RF_HDBG")) : 0;     // timing experiments only (results are wrong): see the kernels
@@ -1046,7 +1050,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     WM_TRY(plan_hier_ws(ctx, p, *ht, (p.B + NQ - 1) / NQ, hw));
     static bool attr_set = false;
     if (!attr_set) {
-      WM_HIP(hipFuncSetAttribute((const void*)k_happly, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HN * 33 * 4));
+      WM_HIP(hipFuncSetAttribute((const void*)k_happly, hipFuncAttributeMaxDynamicSharedMemorySize, HN * 65 * 4));
       attr_set = true;
     }
   }
@@ -1060,12 +1064,12 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     float* par = hw.partials + (size_t)z0 * nsp * HG_TILES * hw.KS * HG_T * HG_T;
     int* skip = hw.skip + (size_t)z0 * nsp * HU;
     int* anyrot = hw.anyrot + (size_t)z0 * nsp;
-    const int n32 = ht->nmax * RB, ntiles = n32 <= HG_T ? 1 : n32 <= 2 * HG_T ? 3 : HG_TILES;
+    const int n32 = ht->nmax * RB, npmax = (n32 + HG_T - 1) / HG_T;
     const int nchunk = (p.M + HG_KC - 1) / HG_KC;
-    const int KS = hier_ks(nsp, nz, ntiles, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
-    const int ngrp = nsp * KS * nz;               // (super-pair, split, plane) groups of ntiles workgroups, dealt over the XCDs
-    hipLaunchKernelGGL(k_hgram, dim3(((ngrp + 7) / 8) * 8 * ntiles), dim3(256), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
-                       par, KS, cps, ntiles, nz, hdbg);
+    const int KS = hier_ks(nsp, nz, npmax, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
+    const int ngrp = nsp * KS * nz;               // (super-pair, split, plane) groups of npmax workgroups, dealt over the XCDs
+    hipLaunchKernelGGL(k_hgram, dim3(((ngrp + 7) / 8) * 8 * npmax), dim3(512), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
+                       par, KS, cps, npmax, nz, hdbg);
     hipLaunchKernelGGL(k_hreduce, dim3(HSB * (HSB + 1) / 2, nsp, nz), dim3(256), 0, st, par, sup, nsp, KS, Gs, Qs, anyrot);
     constexpr int NG = HU * (HU - 1) / 2;
     for (int t = 0; t < ht->T[s1]; ++t) {
@@ -1073,11 +1077,15 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
       hipLaunchKernelGGL(k_rf_inner, dim3(nsp * HU, 1, nz), dim3(INNER_NT), 0, st, (const float*)nullptr, 0, R, w.maxcos + z0,
                          w.floor2 + z0, (s1 == 0 && t == 0) ? 0 : 1, skip, skip_thr, un, Gs, anyrot, nsp);
       const bool last = t + 1 == ht->T[s1];        // nothing reads G_s after the last stage: only Q_s <- Q_s P
-      hipLaunchKernelGGL(k_hupdate, dim3(last ? HU * HU : NG + HU * HU, nsp, nz), dim3(256), 0, st, un, sup, nsp, R, skip, Gs, Qs,
+      constexpr int NQT = (HU / 2) * HU;             // Q tasks: (pair of 64-row slabs, unit)
+      hipLaunchKernelGGL(k_hupdate, dim3(last ? NQT : NG + NQT, nsp, nz), dim3(256), 0, st, un, sup, nsp, R, skip, Gs, Qs,
                          last ? NG : 0);
     }
-    hipLaunchKernelGGL(k_happly, dim3(ctx->n_cu), dim3(64 * ht->nmax), (size_t)2 * n32 * 33 * 4, st, aug, p.aug_ps, p.ld, ncols, sup, nsp,
-                       nz, Qs, anyrot, n32, hdbg >> 4);
+    float* Qpk = hw.Qpk + (size_t)z0 * nsp * HN * HN;
+    hipLaunchKernelGGL(k_hpack, dim3(HSB * HSB / 4, nsp, nz), dim3(256), 0, st, Qs, sup, nsp, anyrot, Qpk);
+    const int ntask = nsp * nz * ((ncols + 63) / 64);
+    hipLaunchKernelGGL(k_happly, dim3(8 * ((ntask + 7) / 8)), dim3(64 * ht->nmax), (size_t)n32 * 65 * 4, st, aug, p.aug_ps, p.ld, ncols,
+                       sup, nsp, nz, Qpk, anyrot, hdbg >> 4);
   };
   while (!done && sweep < MAX_SWEEPS) {
     WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));
@@ -1114,6 +1122,19 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
   }
   *sweeps_out = done ? sweep : -sweep;
   ctx->ref_last_sweeps = sweep;
+  {   // nominal matrix-core flops of one sweep (every pair counted as rotated), for bench.py's roofline
+    double f = 0.0;
+    if (hier) {
+      for (int s1 = 0; s1 < ht->nsteps1; ++s1) {
+        // the host copy of the tables holds the stage counts; the super-pairs' sizes follow from the block counts
+        f += ht->flops_step[s1] * ((double)p.M) + ht->flops_apply_step[s1] * (double)ncols + ht->flops_stage_step[s1];
+      }
+    } else {
+      f = (double)p.nsteps * p.npairs * (2.0 * 3 * RB * RB * p.M + 2.0 * RP * RP * ncols);
+    }
+    ctx->ref_last_flops = f * sweep * p.B;
+    ctx->ref_last_hier = hier ? 1 : 0;
+  }
   return WM_OK;
 }
 
@@ -1785,6 +1806,12 @@ int wm_ref_reconstruct_f32(wm_ctx* ctx, const float* Uw, const float* sw_hat, co
   }
   WM_HIP(hipMemcpyAsync(out, d_full, (size_t)H * W * 4, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
+  return WM_OK;
+}
+
+int wm_ref_last_flops(wm_ctx* ctx, double* flops_out, int* two_level_out) {
+  if (!ctx || !flops_out || !two_level_out) return set_err(WM_ERR_BADARG, "NULL argument");
+  *flops_out = ctx->ref_last_flops; *two_level_out = ctx->ref_last_hier;
   return WM_OK;
 }
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "wm_ref_embed_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i],
     "wm_ref_sigma_u8": [_vp, _vp, _vp, _i, _i, _i],
     "wm_ref_last_sweeps": [_vp, C.POINTER(_i)],
+    "wm_ref_last_flops": [_vp, C.POINTER(C.c_double), C.POINTER(_i)],
     "wm_ref_embed_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_ref_sigma_planes_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
     "wm_ref_embed_planes_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
@@ -455,6 +456,12 @@ class Context:
         n = _i(0)
         self._call("wm_ref_last_sweeps", C.byref(n))
         return n.value
+
+    def ref_last_flops(self):
+        """(matrix-core flops the last full-frame SVD's Gram / rotation products issued, ran the two-level scheme?)"""
+        f = C.c_double(0.0); h = _i(0)
+        self._call("wm_ref_last_flops", C.byref(f), C.byref(h))
+        return f.value, bool(h.value)
 
     def ref_sigma_planes(self, planes: np.ndarray) -> np.ndarray:
         if planes.dtype != np.uint8 or planes.ndim != 3:

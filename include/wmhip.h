@@ -264,6 +264,10 @@ int wm_ref_detect_planes_u8_dev(wm_ctx* ctx, const uint8_t* stego, const float* 
 
 /* Diagnostics: outer Jacobi sweeps the last full-frame SVD on this context needed. */
 int wm_ref_last_sweeps(wm_ctx* ctx, int* sweeps_out);
+/* Diagnostics (roofline accounting of bench.py): matrix-core flops the block Jacobi of the last full-frame SVD on this
+ * context issued - Gram and rotation products as launched, pairs skipped as converged included - and whether it ran the
+ * two-level (super-block) scheme (1) or the flat tournament (0). */
+int wm_ref_last_flops(wm_ctx* ctx, double* flops_out, int* two_level_out);
 
 /* Replaces single:297-301 + _nc (single:284-289): score over all L singular values. */
 int wm_ref_detect_u8(wm_ctx* ctx, const uint8_t* stego, const float* sigma_c, const float* sigma_w,

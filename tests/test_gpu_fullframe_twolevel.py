@@ -1,0 +1,98 @@
+"""The two-level (super-block) block Jacobi of the full-frame mode (csrc/wm_ref_hier.inc).
+
+From 20 planes per call on it is the library's default; below that the flat tournament runs.  Here it is FORCED
+(WM_RF_HIER=1, read by the library on every call) and held against
+  * float64 LAPACK and the flat tournament directly (singular values, sweep counts), for every super-block size, on
+    shapes that exercise 1, 2 and 3 row panels, byes of the level-1 tournament, unequal super-blocks, transposed
+    (portrait) planes, rank-deficient planes and a batch;
+  * the whole existing full-frame suite: the parity tests of tests/test_gpu_fullframe.py are collected a second
+    time in this module under the forced scheme (embed / sigma / detect / extract / watermark-side SVD with its
+    accumulated left factor / rank-deficient planes and their null-space completion / smooth content / 1080p).
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _force_two_level(monkeypatch):
+    monkeypatch.setenv("WM_RF_HIER", "1")
+    yield
+
+
+def _load_base():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_fullframe.py")
+    spec = importlib.util.spec_from_file_location("_ff_base_for_two_level", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_base = _load_base()
+# the existing parity tests, run again under the forced two-level scheme
+test_two_level_embed_sigma_detect = _base.test_fullframe_embed_sigma_detect
+test_two_level_watermark_svd_and_extract = _base.test_fullframe_watermark_svd_and_extract
+test_two_level_batched_planes_equal_single = _base.test_fullframe_batched_planes_equal_single
+test_two_level_rank_deficient_planes = _base.test_fullframe_rank_deficient_planes
+test_two_level_parity_on_smooth_content = _base.test_fullframe_parity_on_smooth_content
+test_two_level_batch_of_mixed_content = _base.test_fullframe_batch_of_mixed_content
+test_two_level_cfg2_1080p_against_float64_lapack = _base.test_fullframe_cfg2_1080p_against_float64_lapack
+test_two_level_random_geometries = _base.test_fullframe_random_geometries
+
+
+def _planes(B, H, W, seed=5):
+    rng = np.random.default_rng(seed)
+    planes = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
+    if B >= 3:      # a smooth plane and a half-empty one in the batch
+        planes[1] = (np.outer(np.linspace(0, 200, H), np.ones(W)) + 20 * np.sin(np.arange(W) / 9.0)[None, :]).astype(np.uint8)
+        planes[2, :, W // 2:] = 0
+    return planes
+
+
+@pytest.mark.parametrize("sb", [6, 4, 2])
+@pytest.mark.parametrize("B,H,W", [(1, 64, 96), (2, 128, 200), (1, 200, 136), (3, 320, 480), (1, 448, 448), (1, 832, 900)])
+def test_two_level_against_lapack_and_the_flat_tournament(gpu_ctx, monkeypatch, sb, B, H, W):
+    planes = _planes(B, H, W)
+    ref = np.stack([np.linalg.svd(p.astype(np.float64), compute_uv=False) for p in planes])
+    monkeypatch.setenv("WM_RF_HIER", "0")
+    s_flat = gpu_ctx.ref_sigma_planes(planes)
+    n_flat = gpu_ctx.ref_last_sweeps()
+    assert gpu_ctx.ref_last_flops()[1] is False
+    monkeypatch.setenv("WM_RF_HIER", "1")
+    monkeypatch.setenv("WM_RF_HIER_SB", str(sb))
+    s = gpu_ctx.ref_sigma_planes(planes)
+    n = gpu_ctx.ref_last_sweeps()
+    flops, two_level = gpu_ctx.ref_last_flops()
+    assert two_level is True and flops > 0
+    assert np.max(np.abs(s - ref) / ref[:, :1]) < 2e-6           # the bar of tests/test_gpu_fullframe.py
+    assert np.max(np.abs(s - s_flat) / ref[:, :1]) < 1e-6
+    assert n <= n_flat + 3                                       # the ordering converges like the flat one (measured: -2 .. +2)
+    gpu_ctx.check_status()
+
+
+def test_two_level_is_deterministic_and_batch_independent(gpu_ctx):
+    """Bit for bit: the same plane alone, twice, and inside a batch (fixed summation orders, no float atomics)."""
+    planes = _planes(3, 256, 384, seed=11)
+    a = gpu_ctx.ref_sigma_planes(planes[:1])
+    b = gpu_ctx.ref_sigma_planes(planes[:1])
+    c = gpu_ctx.ref_sigma_planes(planes)
+    assert np.array_equal(a, b)
+    # a batch sweeps until its slowest plane has converged, so a plane may see extra (skipped or tiny) rotations: equal to
+    # the accuracy of the values, not bit for bit
+    assert np.max(np.abs(c[0] - a[0])) / a[0, 0] < 5e-7
+
+
+def test_default_scheme_follows_the_batch_size(gpu_ctx, monkeypatch):
+    monkeypatch.delenv("WM_RF_HIER", raising=False)
+    small = _planes(2, 64, 96)
+    gpu_ctx.ref_sigma_planes(small)
+    assert gpu_ctx.ref_last_flops()[1] is False
+    big = np.repeat(_planes(1, 64, 96), 24, axis=0)
+    s = gpu_ctx.ref_sigma_planes(big)
+    assert gpu_ctx.ref_last_flops()[1] is True
+    ref = np.linalg.svd(big[0].astype(np.float64), compute_uv=False)
+    assert np.max(np.abs(s - ref[None, :])) / ref[0] < 2e-6
