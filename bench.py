@@ -63,6 +63,10 @@ def parse():
                     help="do not run the rocprofv3 --pmc child passes that measure roofline.traffic / roofline.valu in this run "
                          "(the committed profile is replayed instead, and labelled so)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: initialise the process group (RCCL, world size 1) and issue the per-step broadcast of the "
+                         "watermark's singular values all the same - `bcast_ms_per_step` in the line - so that the first multi-GPU "
+                         "run is not also RCCL's first run")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --backend gloo on a 1-GPU box)")
     return ap.parse_args()
@@ -700,8 +704,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    forced = a.force_collective and world == 1
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced:                                   # no launcher: a rendezvous of one on a free local port
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -729,7 +740,7 @@ def main():
         wys = torch.from_numpy(wys_np).to(dev)
         ctx.svd_tiles_f32_dev(wys.data_ptr(), Uw.data_ptr(), Sw.data_ptr(), Vwt.data_ptr(), 1, H, W, W, H * W)
         torch.cuda.synchronize(dev)
-    shard.broadcast_watermark([Uw, Vwt], src=0)      # extract-side meta: once per watermark
+    shard.broadcast_watermark([Uw, Vwt], src=0, force=forced)      # extract-side meta: once per watermark
     # once per watermark as well: fold the IDCT into the factors (Ux = D^T Uw, Vxt = Vwt D), so the
     # per-frame extract is sigma + a rank-8 product (wm_extract_tiles_px_u8_dev)
     Ux = torch.empty_like(Uw); Vxt = torch.empty_like(Vwt)
@@ -742,7 +753,7 @@ def main():
     pending = [None, None]
 
     def issue_bcast(k):
-        if world > 1:
+        if world > 1 or forced:
             pending[k & 1] = dist.broadcast(Sw_buf[k & 1], src=0, async_op=True)
 
     def step(k, record=None):
@@ -778,11 +789,20 @@ def main():
     for w_ in pending:                                # the broadcast issued for the step after the last one
         if w_ is not None:
             w_.wait()
-    if world > 1:
+    if world > 1 or forced:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ctx.check_status()
+    bcast_ms = None
+    if forced:                                       # the collective on its own: 10 synchronous broadcasts of Sw, then the scalar gather
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
+        for _ in range(10):
+            dist.broadcast(Sw_buf[0], src=0)
+        torch.cuda.synchronize(dev)
+        bcast_ms = (time.perf_counter() - tb) / 10 * 1e3
+        shard.gather_scalars(dt)
 
     embed_ms = [ctx.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(n_ev)]
     embed_ms_avg = float(np.mean(embed_ms)) if embed_ms else float("nan")
@@ -826,9 +846,9 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"tile-mode (8x8) embed+extract, {F} frames/rank/step of {W}x{H} uint8 Y, alpha={alpha}, K=8"
-                                   + (", watermark-sigma RCCL broadcast per step (async, double-buffered)" if world > 1
+                                   + (", watermark-sigma RCCL broadcast per step (async, double-buffered)" if (world > 1 or forced)
                                       else ", single rank: no broadcast"),
-                       "frames_per_rank": F, "height": H, "width": W, "alpha": alpha,
+                       "frames_per_rank": F, "frames_per_launch": F, "height": H, "width": W, "alpha": alpha,
                        "parallelism": f"frames sharded over {world} rank(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -870,9 +890,14 @@ def main():
                 out["full_extract"] = full_extract_section(torch, api, ctx, dev, frames, Sw, Ux, Vxt, stego, sigma_c, wm_out, idx, alpha)
             if "end_to_end" not in skip:
                 out["end_to_end"] = end_to_end_section(torch, api, dev, H, W, alpha, Sw, Ux, Vxt, idx)
+        if forced:
+            out["force_collective"] = {"backend": a.backend, "world_size": 1, "bcast_ms_per_step": bcast_ms,
+                                       "bcast_bytes": int(Sw.numel() * 4),
+                                       "note": "--force-collective: process group of one rank, the per-step broadcast issued asynchronously "
+                                               "inside every timed step as at N > 1; bcast_ms_per_step = the collective alone, synchronous"}
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

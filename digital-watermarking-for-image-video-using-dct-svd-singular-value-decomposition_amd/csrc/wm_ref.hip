@@ -787,6 +787,39 @@ __global__ void k_rf_gather_rows(const float* __restrict__ src, const int ld, co
     dst[(size_t)k * ldd + j] = row[j] * s;
 }
 
+// the sorted, normalised factors of all planes of a batch (grid.z = plane):
+//   straight:    dst[z][k][c] = src[z][order[z][k]][c] * scale[z][k]          (grid: column blocks x rows k)
+//   transposing: dst[z][c][k] = src[z][order[z][k]][c] * scale[z][k]          (32 x 32 tiles through LDS, both sides coalesced)
+__global__ void k_rf_gather_rows_b(const float* __restrict__ src, const size_t src_ps, const int ld, const int ncols,
+                                   const int* __restrict__ order, const float* __restrict__ scale, const int os,
+                                   float* __restrict__ dst, const size_t dst_ps, const int ldd) {
+  const int k = blockIdx.y, z = blockIdx.z;
+  const float* row = src + (size_t)z * src_ps + (size_t)order[(size_t)z * os + k] * ld;
+  const float sc = scale[(size_t)z * os + k];
+  float* d = dst + (size_t)z * dst_ps + (size_t)k * ldd;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ncols; j += gridDim.x * blockDim.x) d[j] = row[j] * sc;
+}
+
+__global__ __launch_bounds__(256) void k_rf_gather_rows_t(const float* __restrict__ src, const size_t src_ps, const int ld, const int ncols,
+                                                         const int nk, const int* __restrict__ order, const float* __restrict__ scale,
+                                                         const int os, float* __restrict__ dst, const size_t dst_ps, const int ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, z = blockIdx.z;
+  const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  src += (size_t)z * src_ps; dst += (size_t)z * dst_ps; order += (size_t)z * os; scale += (size_t)z * os;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (k < nk && c < ncols) ? src[(size_t)order[k] * ld + c] * scale[k] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, k = k0 + tx;
+    if (c < ncols && k < nk) dst[(size_t)c * ldd + k] = tile[tx][ty + 8 * i];
+  }
+}
+
 // deterministic pseudo-random pattern in (-1, 1): the start vectors of the null-space completion
 // (rank-deficient planes); element (r, c) of the matrix with seed `seed`
 __global__ void k_rf_pattern(float* __restrict__ dst, const int cols, const unsigned seed) {
@@ -1650,12 +1683,16 @@ int wm_ref_svd_planes_f32(wm_ctx* ctx, const float* planes, float* U, float* S, 
   const RefPlan p = make_plan(H, W, B);
   RefWs w;
   const size_t n_in = span_of(B, H, W, row_stride, plane_stride);
-  const size_t n_in_a = (n_in + 63) & ~(size_t)63, hw = (size_t)H * W, fl = (size_t)p.M * p.L;
-  // tmp1: input planes | DCT planes [B][H][W] | one plane's sorted factor for download;  tmp2: DCT intermediate [B][H][W], then T = A0 B^T [B][L][Lp]
-  WM_TRY(plan_workspace(ctx, p, w, n_in_a + (size_t)B * hw + fl, std::max((size_t)B * hw, (size_t)B * p.L * p.Lp)));
+  const size_t n_in_a = (n_in + 63) & ~(size_t)63, hw = (size_t)H * W, fl = (size_t)p.L * (p.M + p.L), lp64 = ((size_t)p.Lp + 63) & ~(size_t)63;
+  // tmp1: input planes | DCT planes [B][H][W] | every plane's sorted factors in the caller's layout, U [H][L] | Vt [L][W] | per plane: order, 1 / |q_i|,
+  // 1 / |b_i|;  tmp2: DCT intermediate [B][H][W], then T = A0 B^T [B][L][Lp]
+  WM_TRY(plan_workspace(ctx, p, w, n_in_a + (size_t)B * hw + (size_t)B * fl + 3 * (size_t)B * lp64, std::max((size_t)B * hw, (size_t)B * p.L * p.Lp)));
   float* d_in = w.tmp1;
   float* d_c = d_in + n_in_a;            // [B][H][W]
-  float* d_f = d_c + (size_t)B * hw;     // [L][M] / [L][L]
+  float* d_f = d_c + (size_t)B * hw;     // [B]( U [H][L] | Vt [L][W] )
+  int* d_ord = (int*)(d_f + (size_t)B * fl);
+  float* d_sq = (float*)(d_ord + (size_t)B * lp64);
+  float* d_sb = d_sq + (size_t)B * lp64;
   WM_HIP(hipMemcpyAsync(d_in, planes, n_in * 4, hipMemcpyHostToDevice, ctx->stream));
   const float* src = d_in; size_t src_stride = (size_t)row_stride, src_ps = plane_stride;
   if (apply_dct) {
@@ -1685,8 +1722,8 @@ int wm_ref_svd_planes_f32(wm_ctx* ctx, const float* planes, float* U, float* S, 
   std::vector<double> t2all((size_t)B * p.Lp);
   WM_HIP(hipMemcpyAsync(t2all.data(), w.q2, t2all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
-  std::vector<float> longf((size_t)p.L * p.M), shortf((size_t)p.L * p.L), sq(p.L), sb(p.L), sig;
-  std::vector<int> order;
+  std::vector<float> sq((size_t)B * lp64, 0.0f), sb((size_t)B * lp64, 0.0f), sig;
+  std::vector<int> order, ord_all((size_t)B * lp64, 0);
   for (int z = 0; z < B; ++z) {
     const double* b2z = &b2[(size_t)z * p.Lp]; const double* q2z = &q2[(size_t)z * p.Lp]; const double* t2 = &t2all[(size_t)z * p.Lp];
     std::vector<double> q2s(q2z, q2z + p.Lp);           // q2 itself still normalises the columns of the short-side factor
@@ -1710,30 +1747,35 @@ int wm_ref_svd_planes_f32(wm_ctx* ctx, const float* planes, float* U, float* S, 
     // short-side factor: columns q_i/|q_i|   (rows of Qt), long-side factor: rows b_i/|b_i|
     for (int k = 0; k < p.L; ++k) {
       const int i = order[k];
-      sq[k] = q2z[i] > 0 ? (float)(1.0 / sqrt(q2z[i])) : 0.0f;
-      sb[k] = b2z[i] > 0 ? (float)(1.0 / sqrt(b2z[i])) : 0.0f;
-    }
-    const float* aug_z = w.aug + (size_t)z * p.aug_ps;
-    WM_HIP(hipMemcpyAsync(w.order, order.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
-    // long-side factor rows [L x M]
-    WM_HIP(hipMemcpyAsync(w.scale, sb.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, aug_z, p.ld, p.M, w.order, w.scale, d_f, p.M);
-    WM_HIP(hipMemcpyAsync(longf.data(), d_f, longf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(hipStreamSynchronize(ctx->stream));
-    WM_HIP(hipMemcpyAsync(w.scale, sq.data(), (size_t)p.L * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_rf_gather_rows, dim3(8, p.L), dim3(256), 0, ctx->stream, aug_z + p.M, p.ld, p.L, w.order, w.scale, d_f, p.L);
-    WM_HIP(hipMemcpyAsync(shortf.data(), d_f, shortf.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(hipStreamSynchronize(ctx->stream));
-    // shortf[k][r] = k-th singular vector of the short side at coordinate r; longf[k][c] likewise
-    float* Uz = U + (size_t)z * H * p.L; float* Vtz = Vt + (size_t)z * p.L * W;
-    if (!p.transpose) {      // A = X: U[r][k] = shortf[k][r] (H x L), Vt[k][c] = longf[k][c] (L x W)
-      for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) Uz[(size_t)r * p.L + k] = shortf[(size_t)k * p.L + r];
-      memcpy(Vtz, longf.data(), longf.size() * 4);
-    } else {                 // A = X^T: U[r][k] = longf[k][r] (H x L), Vt[k][c] = shortf[k][c] (L x W)
-      for (int r = 0; r < H; ++r) for (int k = 0; k < p.L; ++k) Uz[(size_t)r * p.L + k] = longf[(size_t)k * p.M + r];
-      memcpy(Vtz, shortf.data(), shortf.size() * 4);
+      ord_all[(size_t)z * lp64 + k] = i;
+      sq[(size_t)z * lp64 + k] = q2z[i] > 0 ? (float)(1.0 / sqrt(q2z[i])) : 0.0f;
+      sb[(size_t)z * lp64 + k] = b2z[i] > 0 ? (float)(1.0 / sqrt(b2z[i])) : 0.0f;
     }
   }
+  WM_HIP(hipMemcpyAsync(d_ord, ord_all.data(), ord_all.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipMemcpyAsync(d_sq, sq.data(), sq.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  WM_HIP(hipMemcpyAsync(d_sb, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  // The factors leave the device in the caller's layout (round 3 downloaded both sorted factors row-major and transposed one
+  // of them on the host, element by element: 5 - 10 ms of a 1080p call, ~0.3 s of an 8K one).
+  //   A = X   (H <= W): U[r][k] = q_k[r] / |q_k|  (transposing gather of the Qt part),  Vt[k][c] = b_k[c] / |b_k|  (straight)
+  //   A = X^T (H >  W): U[r][k] = b_k[r] / |b_k|  (transposing gather of the B part),   Vt[k][c] = q_k[c] / |q_k|  (straight)
+  float* d_u = d_f; float* d_vt = d_f + (size_t)H * p.L;
+  const int lp = (int)lp64;
+  if (!p.transpose) {
+    hipLaunchKernelGGL(k_rf_gather_rows_t, dim3((p.L + 31) / 32, (p.L + 31) / 32, B), dim3(256), 0, ctx->stream, w.aug + p.M, p.aug_ps, p.ld,
+                       p.L, p.L, d_ord, d_sq, lp, d_u, fl, p.L);
+    hipLaunchKernelGGL(k_rf_gather_rows_b, dim3(8, p.L, B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, d_ord, d_sb, lp, d_vt, fl, W);
+  } else {
+    hipLaunchKernelGGL(k_rf_gather_rows_t, dim3((p.M + 31) / 32, (p.L + 31) / 32, B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld,
+                       p.M, p.L, d_ord, d_sb, lp, d_u, fl, p.L);
+    hipLaunchKernelGGL(k_rf_gather_rows_b, dim3(8, p.L, B), dim3(256), 0, ctx->stream, w.aug + p.M, p.aug_ps, p.ld, p.L, d_ord, d_sq, lp, d_vt, fl, W);
+  }
+  WM_HIP(hipGetLastError());
+  for (int z = 0; z < B; ++z) {
+    WM_HIP(hipMemcpyAsync(U + (size_t)z * H * p.L, d_u + (size_t)z * fl, (size_t)H * p.L * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipMemcpyAsync(Vt + (size_t)z * p.L * W, d_vt + (size_t)z * fl, (size_t)p.L * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  WM_HIP(hipStreamSynchronize(ctx->stream));
   return WM_OK;
 }
 

@@ -376,6 +376,9 @@ int wm_copy_mapped_dev(wm_ctx* ctx, void* dst, const void* src, size_t bytes, in
   if (bytes == 0) return WM_OK;
   if (!dst || !src) return set_err(WM_ERR_BADARG, "NULL argument");
   void* d_dst = dst; void* d_src = const_cast<void*>(src);
+  // Only memory the kernel can dereference is accepted: device or managed allocations, and host allocations that are mapped
+  // into the device's address space.  ROCm answers hipSuccess with hipMemoryTypeUnregistered for ordinary pageable host memory
+  // (a kernel touching it faults), so every other type is refused; the range must also lie inside its allocation.
   hipPointerAttribute_t at;
   for (void** pp : {&d_dst, &d_src}) {
     if (hipPointerGetAttributes(&at, *pp) != hipSuccess) { (void)hipGetLastError(); return set_err(WM_ERR_BADARG, "pointer is neither device nor pinned host memory"); }
@@ -383,6 +386,14 @@ int wm_copy_mapped_dev(wm_ctx* ctx, void* dst, const void* src, size_t bytes, in
       void* dp = nullptr;
       if (hipHostGetDevicePointer(&dp, *pp, 0) != hipSuccess || !dp) { (void)hipGetLastError(); return set_err(WM_ERR_BADARG, "host memory is not mapped for the device"); }
       *pp = dp;
+    } else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) {
+      return set_err(WM_ERR_BADARG, "pointer is neither device nor pinned host memory");
+    }
+    void* base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)*pp) == hipSuccess && base && size) {
+      if ((const char*)*pp + bytes > (const char*)base + size) return set_err(WM_ERR_BADARG, "the copy runs past the end of its allocation");
+    } else {
+      (void)hipGetLastError();             // no range known for this pointer (some host registrations): the type check above stands
     }
   }
   if (n_workgroups <= 0) n_workgroups = 64;

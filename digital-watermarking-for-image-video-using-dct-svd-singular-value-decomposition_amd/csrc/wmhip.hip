@@ -533,15 +533,10 @@ __global__ __launch_bounds__(WAVE, WM_FALLBACK_WAVES) void k_embed_fallback(
   }
 }
 
-// Kind 3 of the flagged-tile lists (completed from the fast kernel's B: wm::embed_tile_one_small / embed_tile_from_b) in a kernel of its own, one
-// wave per SIMD: three 8 x 8 arrays and a float64 bilinear form need 314-362 registers; inside k_embed_fallback they pushed
-// the literal chain's 202-228 VGPRs into scratch.  Same list walk.
-// (k_embed_fallback: the tiles listed by the fast kernel, one per lane, a fixed grid striding each list - the counts are only known on
-// the device): first the literal chain with orthonormal completion (wm::embed_tile_completed) for the front list,
-// then the closed form of the constant tiles (wm::embed_tile_constant) for the back list.
-#ifndef WM_FALLBACK_WAVES
-#define WM_FALLBACK_WAVES 2
-#endif
+// Kind 3 of the flagged-tile lists (completed from the fast kernel's B: wm::embed_tile_one_small / embed_tile_from_b) in a
+// kernel of its own, one wave per SIMD: three 8 x 8 arrays and a float64 bilinear form need 314-362 registers; inside
+// k_embed_fallback they pushed the literal chain's 202-228 VGPRs into scratch.  Same list walk as k_embed_fallback (one
+// tile per lane, a fixed grid striding the list - the count is only known on the device).
 template <bool ALIGNED, bool YW>
 __global__ __launch_bounds__(WAVE, 1) void k_embed_one_small(
     const uint8_t* host, const float* __restrict__ sigma_w,

@@ -234,6 +234,8 @@ def _extract_plane_resized(ctx, plane_u8, Sc, Uw, Vwt, alpha, kfrac, k_floor, H,
 def _nc(a, b) -> float:
     """single:284-289"""
     a = np.asarray(a, dtype=np.float32).reshape(-1); b = np.asarray(b, dtype=np.float32).reshape(-1)
+    if a.size == 0 or b.size == 0:
+        return 0.0                                                         # single:286
     a = a - a.mean(); b = b - b.mean()
     return float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-8))
 
@@ -267,8 +269,15 @@ def extract_arrays(stego: np.ndarray, meta, password: str, normalize: bool = Tru
             + [meta["VW" + n + "t"] for n in "bgr"]
     # single:206-209,244-247: the HMAC check runs on a worker thread UNDER the device work (it is 28 ms per 66 MB of factors,
     # more than everything else of a tile-mode extract); nothing is returned before it has passed, and a mismatch takes
-    # precedence over whatever else went wrong meanwhile, as in the reference, where it comes first
+    # precedence over whatever else went wrong meanwhile, as in the reference, where it comes first.  The overlap is only
+    # taken for a key whose permutation is already cached (the extract that follows an embed, the frames of a clip): for any
+    # other key the check is joined BEFORE the expensive key-dependent steps - the PCG64 shuffle of H*W indices, the route
+    # build, the factor upload - so that a wrong password or a tampered meta costs one HMAC, evicts nothing from the
+    # permutation / device-index caches and never reaches the native code (which would otherwise see unauthenticated
+    # factors guarded by its shape checks alone).
     check = _Later(lambda: hg.digests_equal(hg.hmac_digest(key, parts), digest))
+    if not hg.permutation_is_cached(H, W, key) and not check.result():
+        raise ValueError("Sai mật khẩu hoặc meta không khớp.")             # single:208-209,246-247
     try:
         out = _extract_checked(stego, meta, mode, alpha, kfrac, k_floor, H, W, key, normalize, device)
     except BaseException:

@@ -27,7 +27,10 @@ K_FRAC_DEFAULT = 0.6  # single:13
 def _read_png_unfiltered(path: str):
     """Fast path for the PNGs this module writes itself (8-bit gray / RGB, not interlaced, every scanline with filter type
     0): inflate and reshape - no per-pixel unfiltering, a 4K stego in 15 ms instead of 60.  Anything else (other colour
-    types, bit depths, interlacing, a palette, any filtered scanline, a damaged stream) returns None and goes to Pillow."""
+    types, bit depths, interlacing, a palette, any filtered scanline, a damaged stream) returns None and goes to Pillow,
+    whose own checks then decide.  The same guards as Pillow's apply here: every chunk's CRC is verified, an image over
+    ``Image.MAX_IMAGE_PIXELS`` is refused, and the stream is inflated with a bound of exactly the bytes the header
+    announces (+ 1, to notice a longer stream) - a small file cannot be made to allocate more than its header's size."""
     import struct
     import zlib
     try:
@@ -36,10 +39,17 @@ def _read_png_unfiltered(path: str):
         if data[:8] != b"\x89PNG\r\n\x1a\n":
             return None
         pos, idat, ihdr = 8, [], None
-        while pos + 8 <= len(data):
+        while pos + 12 <= len(data):
             (n,), tag = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+            if pos + 12 + n > len(data):
+                return None                                           # truncated chunk
             body = data[pos + 8:pos + 8 + n]
+            (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+            if zlib.crc32(body, zlib.crc32(tag)) & 0xFFFFFFFF != crc:
+                return None                                           # damaged: let Pillow report it
             if tag == b"IHDR":
+                if ihdr is not None or n != 13:
+                    return None
                 ihdr = struct.unpack(">IIBBBBB", body)
             elif tag == b"IDAT":
                 idat.append(body)
@@ -53,9 +63,14 @@ def _read_png_unfiltered(path: str):
         w, h, depth, ctype, _, _, interlace = ihdr
         if depth != 8 or ctype not in (0, 2) or interlace != 0 or w == 0 or h == 0:
             return None
+        limit = Image.MAX_IMAGE_PIXELS
+        if limit is not None and w * h > limit:
+            return None                                               # Pillow's decompression-bomb guard decides
         ch = 1 if ctype == 0 else 3
-        raw = zlib.decompress(b"".join(idat))
-        if len(raw) != h * (1 + w * ch):
+        expect = h * (1 + w * ch)
+        d = zlib.decompressobj()
+        raw = d.decompress(b"".join(idat), expect + 1)                # never materialises more than the header's size
+        if len(raw) != expect or d.unconsumed_tail or not d.eof:
             return None
         a = np.frombuffer(raw, np.uint8).reshape(h, 1 + w * ch)
         if a[:, 0].any():
@@ -293,6 +308,12 @@ _perm_lock = threading.Lock()
 _PERM_CACHE_ENTRIES = 2
 
 
+def permutation_is_cached(H: int, W: int, key: bytes) -> bool:
+    """Whether permutation_index(H, W, key) would be served from the cache (an authenticated key's index usually is)."""
+    with _perm_lock:
+        return (int(H), int(W), bytes(key)) in _perm_cache
+
+
 def permutation_index(H: int, W: int, key: bytes) -> np.ndarray:
     """``idx = np.arange(H*W); rng.shuffle(idx)`` (single:68-69,124,219,265):
     bit-exact because it *is* the same NumPy PCG64 call.  The shuffle is sequential host work
@@ -339,6 +360,7 @@ def save_npz(path: str, arrays: dict, compressed: bool = True, threads: int = 32
     import struct
     import zlib
     from concurrent.futures import ThreadPoolExecutor
+    path = os.fspath(path)                          # np.savez accepts os.PathLike too
     if not path.endswith(".npz"):
         path = path + ".npz"
     items = [(k, np.asanyarray(v)) for k, v in arrays.items()]
@@ -349,10 +371,15 @@ def save_npz(path: str, arrays: dict, compressed: bool = True, threads: int = 32
     # every member's deflate stream in 1 MiB chunks on worker threads (_deflate_chunks), its CRC beside them
     heads, datas = [], []
     for name, a in items:
+        # the header describes the array whose bytes are written: the C-contiguous copy (a Fortran-ordered or transposed
+        # member would otherwise be announced as fortran_order=True over C-ordered bytes and load scrambled)
+        c = np.ascontiguousarray(a)
+        if a.ndim == 0:
+            c = c.reshape(())                       # ascontiguousarray promotes 0-d to 1-d
         head = io.BytesIO()
-        np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(a))
+        np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(c))
         heads.append(head.getvalue())
-        datas.append(np.ascontiguousarray(a).reshape(-1).view(np.uint8) if a.size else np.zeros(0, np.uint8))
+        datas.append(c.reshape(-1).view(np.uint8) if c.size else np.zeros(0, np.uint8))
     with ThreadPoolExecutor(max_workers=max(1, min(threads, len(items)))) as ex:
         crcs = [ex.submit(lambda i=i: zlib.crc32(datas[i], zlib.crc32(heads[i])) & 0xFFFFFFFF) for i in range(len(items))]
         comps = _deflate_chunks(list(zip(heads, datas)), 6, threads)

@@ -28,12 +28,16 @@ def all_ranges(world_size: int, n_frames: int):
     return [frame_range(r, world_size, n_frames) for r in range(world_size)]
 
 
-def broadcast_watermark(tensors, src: int = 0, group=None):
+def broadcast_watermark(tensors, src: int = 0, group=None, force: bool = False):
     """Broadcast the watermark decomposition tensors (Sw[, Uw, Vwt]) from
-    ``src`` in place.  No-op without an initialised process group (1 GPU)."""
+    ``src`` in place.  No-op without an initialised process group (1 GPU), or with
+    a group of one rank unless ``force`` (the collective is then issued all the
+    same: a single-GPU rehearsal of the RCCL call the N > 1 runs make)."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensors
+    if dist.get_world_size(group) == 1 and not force:
         return tensors
     for t in tensors:
         dist.broadcast(t, src=src, group=group)

@@ -221,30 +221,85 @@ def test_constant_tile_closed_form_equals_the_literal_chain(hh):
 
 
 def test_tile_math_under_sanitizers(tmp_path):
-    """AddressSanitizer + UBSan over the tile arithmetic (CPU build only - GPU
-    sanitizers are not available on this pool)."""
+    """AddressSanitizer + UndefinedBehaviorSanitizer over the whole CPU build of the tile arithmetic and its shim
+    (tests/host_harness.cpp = csrc/wm_tile_math.h behind the same entry-point shapes as the C ABI) - CPU only: GPU
+    sanitizers are not available on this pool.  One driver walks EVERY harness entry
+    point - the packed fast path with its flagged-tile classes, the literal chain, sigma-only, the watermark-side SVD,
+    extract, the closed forms (constant / rank-1 tiles) and the DCT - over noise, flat, saturated, striped (rank-1) and
+    ragged (H, W not multiples of 8, row_stride > W) planes; any out-of-bounds access, misaligned or overflowing
+    operation aborts the run (-fno-sanitize-recover=all)."""
     exe = str(tmp_path / "hh_asan")
     main = str(tmp_path / "main.cpp")
     open(main, "w").write(r'''
 #include <vector>
 #include <cstdio>
 #include <cstdint>
-extern "C" int hh_embed_tiles_u8_pk(const uint8_t*, const float*, uint8_t*, float*, float*, int, int, int, float, int, int*, int*);
-extern "C" int hh_sigma_tiles_u8_pk(const uint8_t*, float*, int, int, int, int*);
+#include <cmath>
+extern "C" {
+int hh_embed_tiles_u8(const uint8_t*, const float*, uint8_t*, float*, float*, int, int, int, float, int, int*);
+int hh_sigma_tiles_u8(const uint8_t*, float*, int, int, int);
+int hh_svd_tiles_f32(const float*, float*, float*, float*, int, int, int);
+int hh_extract_tiles_u8(const uint8_t*, const float*, const float*, const float*, float*, int, int, int, float, int);
+int hh_embed_tiles_u8_pk(const uint8_t*, const float*, uint8_t*, float*, float*, int, int, int, float, int, int*, int*);
+int hh_sigma_tiles_u8_pk(const uint8_t*, float*, int, int, int, int*);
+void hh_constant_tile_both_ways(float, const float*, const float*, float*, float*, float*, float*);
+int hh_rank1_tile_both_ways(const uint8_t*, const float*, const float*, float*, float*, float*, float*);
+void hh_dct8x8(float*, int);
+}
+static unsigned lcg(unsigned& x) { x = x * 1664525u + 1013904223u; return x >> 24; }
 int main() {
-  const int H = 40, W = 56; std::vector<uint8_t> h(H * W), s(H * W); std::vector<float> sw((H/8)*(W/8)*8, 5.f), sc(sw.size()), yw(H * W);
-  unsigned x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = x >> 24; }
-  int ms = 0, nf = 0;
-  hh_embed_tiles_u8_pk(h.data(), sw.data(), s.data(), sc.data(), yw.data(), H, W, W, 0.15f, 8, &ms, &nf);
-  hh_sigma_tiles_u8_pk(s.data(), sc.data(), H, W, W, nullptr);
-  std::printf("ok %d %d\n", ms, nf); return 0; }
+  unsigned seed = 12345;
+  int total = 0;
+  const int geo[4][3] = {{40, 56, 56}, {43, 61, 64}, {8, 8, 8}, {24, 100, 128}};     // H, W, row_stride (ragged ones too)
+  for (int content = 0; content < 5; ++content)
+    for (auto& g : geo) {
+      const int H = g[0], W = g[1], RS = g[2], nt = (H / 8) * (W / 8);
+      std::vector<uint8_t> h((size_t)H * RS), s((size_t)H * RS), s2((size_t)H * RS);
+      for (int r = 0; r < H; ++r)
+        for (int c = 0; c < RS; ++c) {
+          uint8_t v;
+          switch (content) {
+            case 0: v = (uint8_t)lcg(seed); break;                       // noise
+            case 1: v = 77; break;                                       // flat
+            case 2: v = (c / 8 % 2) ? 255 : 0; break;                    // saturated blocks
+            case 3: v = (uint8_t)(10 + 20 * (c % 8)); break;             // every row equal: rank-1 tiles
+            default: v = (r % 8 == 3) ? 200 : 30; break;                 // one-pixel rules: rank-1 tiles of the other kind
+          }
+          h[(size_t)r * RS + c] = v;
+        }
+      std::vector<float> sw((size_t)nt * 8 + 8), sc(sw.size()), sc2(sw.size()), yw((size_t)H * W), wm((size_t)H * W);
+      for (size_t i = 0; i < sw.size(); ++i) sw[i] = 40.0f / (1 + i % 8);
+      for (int K : {8, 3}) {
+        int ms = 0, nf = 0, hist[16] = {0};
+        total += hh_embed_tiles_u8_pk(h.data(), sw.data(), s.data(), sc.data(), yw.data(), H, W, RS, 0.15f, K, &ms, &nf);
+        total += hh_embed_tiles_u8(h.data(), sw.data(), s2.data(), sc2.data(), nullptr, H, W, RS, 0.15f, K, &ms);
+        total += hh_sigma_tiles_u8_pk(s.data(), sc2.data(), H, W, RS, hist);
+        total += hh_sigma_tiles_u8(s2.data(), sc2.data(), H, W, RS);
+        std::vector<float> plane((size_t)H * W), U((size_t)nt * 64 + 64), S((size_t)nt * 8 + 8), Vt((size_t)nt * 64 + 64);
+        for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) plane[(size_t)r * W + c] = (float)h[(size_t)r * RS + c];
+        total += hh_svd_tiles_f32(plane.data(), U.data(), S.data(), Vt.data(), H, W, W);
+        total += hh_extract_tiles_u8(s.data(), sc.data(), U.data(), Vt.data(), wm.data(), H, W, RS, 0.15f, K);
+      }
+    }
+  float swt[8] = {50, 40, 30, 20, 10, 5, 2, 1}, ak[8] = {.15f, .15f, .15f, .15f, .15f, 0, 0, 0};
+  float y1[64], y2[64], s1[8], s2[8];
+  for (float v : {0.0f, 1.0f, 128.0f, 255.0f}) hh_constant_tile_both_ways(v, swt, ak, y1, s1, y2, s2);
+  uint8_t tile[64];
+  for (int kind = 0; kind < 3; ++kind) {
+    for (int r = 0; r < 8; ++r) for (int c = 0; c < 8; ++c) tile[r * 8 + c] = kind == 0 ? (uint8_t)(3 * r + 1) : kind == 1 ? (uint8_t)(c == 4 ? 250 : 9) : (uint8_t)lcg(seed);
+    total += hh_rank1_tile_both_ways(tile, swt, ak, y1, s1, y2, s2);
+  }
+  float d[64]; for (int i = 0; i < 64; ++i) d[i] = (float)lcg(seed);
+  hh_dct8x8(d, 0); hh_dct8x8(d, 1);
+  std::printf("ok %d\n", total); return 0; }
 ''')
     src = os.path.join(ge.ROOT, "tests", "host_harness.cpp")
     r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                         src, main, "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
-    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
 
 
 def test_rank1_closed_form(hh):

@@ -224,3 +224,88 @@ def test_read_image_fast_path_equals_pillow(tmp_path):
     inter = str(tmp_path / "bad.png"); open(inter, "wb").write(open(own, "rb").read()[:200])                  # truncated file
     with pytest.raises(ValueError, match="Không mở được ảnh"):
         hg.read_image_bgr(inter)
+
+
+def test_save_npz_members_in_any_memory_order_and_pathlike(tmp_path):
+    """a Fortran-ordered or transposed member must load back as the same array (the header has to describe the
+    C-ordered bytes that are written), 0-d and empty members keep their shape, and os.PathLike targets work like np.savez's."""
+    import pathlib
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(37, 53)).astype(np.float32)
+    arrays = {"c": a, "f": np.asfortranarray(a), "t": a.T, "strided": a[::2, 1::3], "f3": np.asfortranarray(rng.normal(size=(4, 5, 6))),
+              "scalar": np.float32(0.12), "empty": np.zeros((0, 8), np.float32), "i": np.arange(12, dtype=np.int64).reshape(3, 4).T}
+    out = hg.save_npz(pathlib.Path(tmp_path) / "meta_any_order", arrays)
+    assert out.endswith("meta_any_order.npz") and os.path.exists(out)
+    with np.load(out, allow_pickle=False) as z:
+        assert sorted(z.files) == sorted(arrays)
+        for k, v in arrays.items():
+            got = z[k]
+            assert got.shape == np.asarray(v).shape and got.dtype == np.asarray(v).dtype, k
+            assert np.array_equal(got, np.asarray(v)), k
+
+
+def _png_chunks(data):
+    import struct
+    pos, out = 8, []
+    while pos + 12 <= len(data):
+        (n,) = struct.unpack(">I", data[pos:pos + 4])
+        out.append((data[pos + 4:pos + 8], pos, n))
+        pos += 12 + n
+    return out
+
+
+def test_png_fast_path_refuses_damaged_and_oversized_streams(tmp_path):
+    """the module's own PNG reader verifies chunk CRCs, inflates with a bound of the header's size and honours
+    Pillow's pixel limit; what it refuses falls through to Pillow, whose error becomes the reference's ValueError."""
+    import struct
+    import zlib
+    from PIL import Image
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    img = np.random.default_rng(1).integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    good = str(tmp_path / "good.png")
+    assert hg.write_png(good, img)
+    assert np.array_equal(hg._read_png_unfiltered(good), img)
+    data = bytearray(open(good, "rb").read())
+    # 1. one flipped byte inside IDAT: the chunk CRC no longer matches -> not the fast path's business
+    tag, pos, n = [c for c in _png_chunks(bytes(data)) if c[0] == b"IDAT"][0]
+    bad = bytearray(data); bad[pos + 8 + n // 2] ^= 0x40
+    p_bad = str(tmp_path / "badcrc.png"); open(p_bad, "wb").write(bytes(bad))
+    assert hg._read_png_unfiltered(p_bad) is None
+    with pytest.raises(ValueError):
+        hg.read_image_bgr(p_bad)                      # Pillow refuses it as well: the reference's "cannot open" error
+    # 2. an IDAT that inflates to far more than the header announces (a 24 x 40 header over 8 MB of zeros, valid CRCs)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(d, zlib.crc32(t)) & 0xFFFFFFFF)
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 40, 24, 8, 2, 0, 0, 0)) \
+        + chunk(b"IDAT", zlib.compress(bytes(8 << 20), 9)) + chunk(b"IEND", b"")
+    p_bomb = str(tmp_path / "bomb.png"); open(p_bomb, "wb").write(bomb)
+    import tracemalloc
+    tracemalloc.start()
+    assert hg._read_png_unfiltered(p_bomb) is None
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert peak < (1 << 20)                           # never materialised the 8 MB
+    # 3. a header over Pillow's pixel limit is left to Pillow's own guard
+    old = Image.MAX_IMAGE_PIXELS
+    try:
+        Image.MAX_IMAGE_PIXELS = 100
+        assert hg._read_png_unfiltered(good) is None
+    finally:
+        Image.MAX_IMAGE_PIXELS = old
+    # 4. a truncated file
+    p_tr = str(tmp_path / "trunc.png"); open(p_tr, "wb").write(bytes(data[:len(data) - 20]))
+    assert hg._read_png_unfiltered(p_tr) is None
+
+
+def test_nc_of_empty_vectors_is_zero():
+    """single:286: an empty Sw / S in a meta gives 0.0 (detect -> False), not NaN."""
+    import ast
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), PKG_NAME, "dct_svd_core_secure.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "_nc"][0]
+    ns = {"np": np}
+    exec(compile(ast.Module([fn], []), "_nc", "exec"), ns)
+    assert ns["_nc"](np.zeros(0, np.float32), np.zeros(0, np.float32)) == 0.0
+    assert ns["_nc"](np.zeros(0), np.arange(4.0)) == 0.0
+    assert abs(ns["_nc"](np.arange(8.0), 2 * np.arange(8.0) + 1) - 1.0) < 1e-6
