@@ -574,7 +574,11 @@ def live_pmc_section(a, F, H, W, timeout_s=150):
         clk = vals["GRBM_GUI_ACTIVE"] / 8 / t                          # summed over the 8 XCDs
         n_waves = F * (((H // 8) * (W // 8) + 63) // 64)
         return {"traffic": fetch_b + write_b, "fetch_bytes_x2_corrected": fetch_b, "write_bytes": write_b,
-                "valu": {"busy_frac_pmc": vals["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t * clk),
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; the denominator is SIMDs x kernel time x a clock
+                # ESTIMATED from GRBM_GUI_ACTIVE (sum over the 8 XCDs, reads a few % high on sub-ms dispatches): the raw ratio can
+                # exceed 1 by that error, so the fraction is capped and the raw figure kept beside it
+                "valu": {"busy_frac_pmc": min(1.0, vals["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t * clk)),
+                         "busy_ratio_raw_uncapped": vals["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t * clk),
                          "insts_per_64_tile_wave": vals["SQ_INSTS_VALU"] / n_waves, "effective_clock_GHz": clk / 1e9,
                          "kernel_us_under_pmc": t * 1e6,
                          "source": "measured in this run: child `rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU "

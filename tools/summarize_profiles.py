@@ -67,11 +67,16 @@ def main():
         n_waves = F * (((H // 8) * (W // 8) + 63) // 64)
         out["embed"] = dict(
             algorithmic_bytes_per_launch=3.0 * H * W * F,
+            # the bench line's roofline.frac from THIS file: algorithmic bytes / kernel-trace average duration / 8 TB/s (the line itself
+            # divides by HIP-event time un-profiled, a few % shorter)
+            roofline_frac_kernel_trace=3.0 * H * W * F / (e["avg_us_kernel_trace"] * 1e-6) / 8e12,
+            roofline_frac_bench_line=bench["roofline"]["frac"],
             fetch_bytes_x2_corrected=fetch_b, write_bytes=write_b,
             hbm_bytes_per_launch=fetch_b + write_b,
             traffic_over_algorithmic=(fetch_b + write_b) / (3.0 * H * W * F),
             valu_insts_per_wave=e["SQ_INSTS_VALU"] / n_waves,
-            valu_busy_fraction=e["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t * clk),
+            valu_busy_fraction=min(1.0, e["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t * clk)),       # capped: the clock is an estimate (GRBM_GUI_ACTIVE)
+            valu_busy_ratio_raw_uncapped=e["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t * clk),
             effective_clock_GHz=clk / 1e9,
             wave_instr_per_s=e["SQ_INSTS_VALU"] / (e["avg_us_kernel_trace"] * 1e-6))
         json.dump(dict(hbm_bytes_per_launch_at_bench_shape=fetch_b + write_b,
