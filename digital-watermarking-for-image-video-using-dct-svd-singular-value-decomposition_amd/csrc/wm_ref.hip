@@ -284,7 +284,8 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
                                                       const float* __restrict__ floor2, const int cross_only,
                                                       int* __restrict__ skip_flags, const float skip_thr,
                                                       const int* __restrict__ h_units, float* __restrict__ h_Gs,
-                                                      int* __restrict__ h_anyrot, const int h_nsp) {
+                                                      int* __restrict__ h_anyrot, const int h_nsp,
+                                                      float* __restrict__ h_Rpk, int* __restrict__ h_skipT) {
   // h_units != NULL: two-level scheme.  blockIdx.x = super-pair * HU + unit; the unit's two 32-row blocks (local
   // indices la, lb of the super-pair) are read straight out of the tracked Gram matrix G_s (no partial sums), and
   // the rotated 64 x 64 matrix R^T G R is written back into G_s at the end.
@@ -416,10 +417,16 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
     // apply kernel skips the pair's rows as well
     s_skip = (m < skip_thr) ? 1 : 0;
     skip_flags[(size_t)blockIdx.z * gridDim.x + p] = s_skip;
+    if (h_skipT) h_skipT[(size_t)blockIdx.z * gridDim.x + p] = s_skip;       // this stage's copy, read by k_happly at the end of the super-step
   }
   __syncthreads();
   if (s_skip) return;
   if (h_units && t == 0) h_anyrot[(size_t)blockIdx.z * h_nsp + p / HU] = 1;     // this super-pair's rows do get rotated
+  // two-level scheme: R also in the order k_happly's waves consume it - for the wave that owns output rows 32 hf .. of the
+  // pair, lane (j, h), MFMA step kk: R[2 kk + h][32 hf + j] at ((hf * 8 + kk / 4) * 64 + j + 32 h) * 4 + kk % 4, so that four
+  // steps' operands are one 16-byte load and a wave's load is 1 KB contiguous
+  float* rpk = h_Rpk ? h_Rpk + ((size_t)blockIdx.z * gridDim.x + p) * RP * RP : nullptr;
+  auto pk_index = [](const int r, const int c) { return (((c >> 5) * 8 + (r >> 3)) * 64 + (c & 31) + 32 * (r & 1)) * 4 + ((r >> 1) & 3); };
   // two-level scheme: the rotated Gram matrix (pitch RP + 1 in LDS) goes back into G_s
   auto writeback = [&](const float* gf) {
     for (int f = t; f < RP * RP / 4; f += INNER_NT) {
@@ -558,6 +565,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
       const int r = kr + INNER_KR * j;
       out[r * RP + k2] = ri[j];
       out[r * RP + RB + k2] = rj[j];
+      if (rpk) { rpk[pk_index(r, k2)] = ri[j]; rpk[pk_index(r, RB + k2)] = rj[j]; }
     }
     if (h_units) writeback(gbuf0);             // 32 steps: the result is back in buffer 0, behind the last step's barrier
 #if defined(WM_INNER_DIAG)
@@ -637,7 +645,10 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #if defined(WM_INNER_DIAG)
   st3 = __builtin_amdgcn_s_memtime();
 #endif
-  for (int e = t; e < RP * RP; e += INNER_NT) out[e] = R[e >> 6][e & 63];
+  for (int e = t; e < RP * RP; e += INNER_NT) {
+    out[e] = R[e >> 6][e & 63];
+    if (rpk) rpk[pk_index(e >> 6, e & 63)] = R[e >> 6][e & 63];
+  }
   if (h_units) writeback(&G[0][0]);
 #if defined(WM_INNER_DIAG)
   __syncthreads();
@@ -1060,7 +1071,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
                          w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1, w.skip + (size_t)z0 * p.npairs,
-                         skip_thr, (const int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
+                         skip_thr, (const int*)nullptr, (float*)nullptr, (int*)nullptr, 0, (float*)nullptr, (int*)nullptr);
       const int n_blk = (ncols + 31) / 32, per_wg = 4 * p.apply_tiles;     // 32-column blocks, 4 waves per workgroup
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_blk + per_wg - 1) / per_wg, nz), dim3(256), 0, st,
                          aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R, w.skip + (size_t)z0 * p.npairs);
@@ -1092,33 +1103,35 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     const HSuper* sup = ht->d_super + (size_t)s1 * nsp;
     float* aug = w.aug + (size_t)z0 * p.aug_ps;
     float* Gs = hw.Gs + (size_t)z0 * nsp * HN * HN;
-    float* Qs = hw.Qs + (size_t)z0 * nsp * HN * HN;
     float* R = hw.R + (size_t)z0 * nsp * HU * RP * RP;
     float* par = hw.partials + (size_t)z0 * nsp * HG_TILES * hw.KS * HG_T * HG_T;
     int* skip = hw.skip + (size_t)z0 * nsp * HU;
     int* anyrot = hw.anyrot + (size_t)z0 * nsp;
+    // per-stage rotations (packed) and skip flags of this group's planes: [stage][plane][super-pair * HU + unit]
+    float* Rpk = hw.Rpk + (size_t)z0 * HT_MAX * nsp * HU * RP * RP;
+    int* skipT = hw.skipT + (size_t)z0 * HT_MAX * nsp * HU;
+    const size_t rpk_stage = (size_t)nz * nsp * HU * RP * RP, skip_stage = (size_t)nz * nsp * HU;
     const int n32 = ht->nmax * RB, npmax = (n32 + HG_T - 1) / HG_T;
     const int nchunk = (p.M + HG_KC - 1) / HG_KC;
     const int KS = hier_ks(nsp, nz, npmax, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
     const int ngrp = nsp * KS * nz;               // (super-pair, split, plane) groups of npmax workgroups, dealt over the XCDs
     hipLaunchKernelGGL(k_hgram, dim3(((ngrp + 7) / 8) * 8 * npmax), dim3(512), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
                        par, KS, cps, npmax, nz, hdbg);
-    hipLaunchKernelGGL(k_hreduce, dim3(HSB * (HSB + 1) / 2, nsp, nz), dim3(256), 0, st, par, sup, nsp, KS, Gs, Qs, anyrot);
+    hipLaunchKernelGGL(k_hreduce, dim3(HSB * (HSB + 1) / 2, nsp, nz), dim3(256), 0, st, par, sup, nsp, KS, Gs, anyrot);
     constexpr int NG = HU * (HU - 1) / 2;
-    for (int t = 0; t < ht->T[s1]; ++t) {
-      const int* un = ht->d_units + (size_t)(ht->stage_off[s1] + t) * nsp * HU;
+    const int T = ht->T[s1];
+    const int* un0 = ht->d_units + (size_t)ht->stage_off[s1] * nsp * HU;
+    for (int t = 0; t < T; ++t) {
+      const int* un = un0 + (size_t)t * nsp * HU;
       hipLaunchKernelGGL(k_rf_inner, dim3(nsp * HU, 1, nz), dim3(INNER_NT), 0, st, (const float*)nullptr, 0, R, w.maxcos + z0,
-                         w.floor2 + z0, (s1 == 0 && t == 0) ? 0 : 1, skip, skip_thr, un, Gs, anyrot, nsp);
-      const bool last = t + 1 == ht->T[s1];        // nothing reads G_s after the last stage: only Q_s <- Q_s P
-      constexpr int NQT = (HU / 2) * HU;             // Q tasks: (pair of 64-row slabs, unit)
-      hipLaunchKernelGGL(k_hupdate, dim3(last ? NQT : NG + NQT, nsp, nz), dim3(256), 0, st, un, sup, nsp, R, skip, Gs, Qs,
-                         last ? NG : 0);
+                         w.floor2 + z0, (s1 == 0 && t == 0) ? 0 : 1, skip, skip_thr, un, Gs, anyrot, nsp, Rpk + t * rpk_stage,
+                         skipT + t * skip_stage);
+      if (t + 1 < T)                               // nothing reads G_s after the last stage
+        hipLaunchKernelGGL(k_hupdate, dim3(NG, nsp, nz), dim3(256), 0, st, un, sup, nsp, R, skip, Gs);
     }
-    float* Qpk = hw.Qpk + (size_t)z0 * nsp * HN * HN;
-    hipLaunchKernelGGL(k_hpack, dim3(HSB * HSB / 4, nsp, nz), dim3(256), 0, st, Qs, sup, nsp, anyrot, Qpk);
     const int ntask = nsp * nz * ((ncols + 63) / 64);
     hipLaunchKernelGGL(k_happly, dim3(8 * ((ntask + 7) / 8)), dim3(64 * ht->nmax), (size_t)n32 * 65 * 4, st, aug, p.aug_ps, p.ld, ncols,
-                       sup, nsp, nz, Qpk, anyrot, hdbg >> 4);
+                       sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot, hdbg >> 4);
   };
   while (!done && sweep < MAX_SWEEPS) {
     WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));
