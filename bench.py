@@ -50,10 +50,10 @@ def parse():
     ap.add_argument("--mode", choices=("tile", "fullframe"), default="tile",
                     help="tile: the 8x8 hot path (contract default); fullframe: the reference's own "
                          "semantics (one dense SVD per plane), secondary workload")
-    ap.add_argument("--ff-frames", type=int, default=48,
-                    help="full-frame section: planes per rank per step (rounds 3: 16; from 20 planes per call on the library runs the "
-                         "two-level block Jacobi, which keeps gaining up to ~48: 139 / 158 / 169 / 178 frames/s at 16 / 24 / 32 / 48 - "
-                         "the 16-plane figure is still reported as value_at_16_planes)")
+    ap.add_argument("--ff-frames", type=int, default=64,
+                    help="full-frame section: planes per rank per step (round 3: 16).  The two-level block Jacobi with its split-f16 "
+                         "products keeps gaining up to ~64 planes per call: 180 / 201 / 214 / 232 / 242 frames/s at 16 / 24 / 32 / 48 / 64 "
+                         "(the flat tournament: 138-142 throughout); the 16-plane figure is still reported as value_at_16_planes")
     ap.add_argument("--ff-height", type=int, default=1080)
     ap.add_argument("--ff-width", type=int, default=1920)
     ap.add_argument("--no-fullframe", action="store_true", help="skip the full-frame section of the default line")

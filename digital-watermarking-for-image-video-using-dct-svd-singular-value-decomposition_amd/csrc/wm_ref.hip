@@ -48,7 +48,9 @@ constexpr float CONV_COS_SIGMA = 2e-4f;
 constexpr float SKIP_FRACTION = 0.25f;    // a block pair below this fraction of the (embed) stopping cosine is left alone
 constexpr double RESIDUE_RHO = 10.0;      // |A0 b_i^T| / |b_i|^2 above this: b_i is not a singular direction at all
 constexpr double T_SWITCH = 200.0;        // |A0 b_i^T| / |b_i| is used for s_i >= T_SWITCH * (residual cosine) * s_max
-constexpr int HIER_MIN_PLANES = 20;        // planes per call from which the two-level scheme (wm_ref_hier.inc) is the default
+constexpr int HIER_F16_DEFAULT = 3;         // two-level scheme, split-f16 operands on the f16 matrix pipe: bit 0 Gram tiles (k_hgram_h), bit 1 rotation products (k_happly_h); WM_RF_HIER_F16 overrides
+constexpr int HIER_MIN_PLANES = 20;         // ... with the f32 kernels
+constexpr int HIER_MIN_PLANES_F16 = 3;      // planes per call from which the two-level scheme is the default when its split-f16 kernels apply        // planes per call from which the two-level scheme (wm_ref_hier.inc) is the default
 constexpr int DEFAULT_QUEUES = 2;         // plane groups of a batched Jacobi, each on its own HIP queue
 constexpr double DRIFT_TOL = 1e-2;        // |T[:, i]| / |b_i|^2 may differ from 1 by the scale drift, not more
 constexpr double NULL_ROW_RATIO = 1e-5;   // rows below this fraction of |A|_F do not take part in the convergence test
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
                                                       int* __restrict__ skip_flags, const float skip_thr,
                                                       const int* __restrict__ h_units, float* __restrict__ h_Gs,
                                                       int* __restrict__ h_anyrot, const int h_nsp,
-                                                      float* __restrict__ h_Rpk, int* __restrict__ h_skipT) {
+                                                      float* __restrict__ h_Rpk, int* __restrict__ h_skipT, const int h_f16) {
   // h_units != NULL: two-level scheme.  blockIdx.x = super-pair * HU + unit; the unit's two 32-row blocks (local
   // indices la, lb of the super-pair) are read straight out of the tracked Gram matrix G_s (no partial sums), and
   // the rotated 64 x 64 matrix R^T G R is written back into G_s at the end.
@@ -427,6 +429,17 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   // steps' operands are one 16-byte load and a wave's load is 1 KB contiguous
   float* rpk = h_Rpk ? h_Rpk + ((size_t)blockIdx.z * gridDim.x + p) * RP * RP : nullptr;
   auto pk_index = [](const int r, const int c) { return (((c >> 5) * 8 + (r >> 3)) * 64 + (c & 31) + 32 * (r & 1)) * 4 + ((r >> 1) & 3); };
+  // h_f16: the same 16 KB as split f16 for k_happly_h (v_mfma_f32_32x32x16_f16: lane (i, kg) holds 8 consecutive k):
+  // R[k][c] = hi + lo' / 2048 with hi = f16(R) (0 below f16's normal range), lo' = f16((R - hi) * 2048);
+  // half index ((c / 32 * 4 + k / 16) * 64 + c % 32 + 32 * (k / 8 % 2)) * 8 + k % 8, hi in the first 4096 halfs, lo' behind
+  auto put_r = [&](const int r, const int c, const float v) {
+    if (!h_f16) { rpk[pk_index(r, c)] = v; return; }
+    _Float16* hp = reinterpret_cast<_Float16*>(rpk);
+    const int idx = (((c >> 5) * 4 + (r >> 4)) * 64 + (c & 31) + 32 * ((r >> 3) & 1)) * 8 + (r & 7);
+    const _Float16 hi = fabsf(v) < 6.2e-5f ? (_Float16)0.0f : (_Float16)v;
+    hp[idx] = hi;
+    hp[RP * RP + idx] = (_Float16)((v - (float)hi) * 2048.0f);
+  };
   // two-level scheme: the rotated Gram matrix (pitch RP + 1 in LDS) goes back into G_s
   auto writeback = [&](const float* gf) {
     for (int f = t; f < RP * RP / 4; f += INNER_NT) {
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
       const int r = kr + INNER_KR * j;
       out[r * RP + k2] = ri[j];
       out[r * RP + RB + k2] = rj[j];
-      if (rpk) { rpk[pk_index(r, k2)] = ri[j]; rpk[pk_index(r, RB + k2)] = rj[j]; }
+      if (rpk) { put_r(r, k2, ri[j]); put_r(r, RB + k2, rj[j]); }
     }
     if (h_units) writeback(gbuf0);             // 32 steps: the result is back in buffer 0, behind the last step's barrier
 #if defined(WM_INNER_DIAG)
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #endif
   for (int e = t; e < RP * RP; e += INNER_NT) {
     out[e] = R[e >> 6][e & 63];
-    if (rpk) rpk[pk_index(e >> 6, e & 63)] = R[e >> 6][e & 63];
+    if (rpk) put_r(e >> 6, e & 63, R[e >> 6][e & 63]);
   }
   if (h_units) writeback(&G[0][0]);
 #if defined(WM_INNER_DIAG)
@@ -1071,7 +1084,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
                          w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1, w.skip + (size_t)z0 * p.npairs,
-                         skip_thr, (const int*)nullptr, (float*)nullptr, (int*)nullptr, 0, (float*)nullptr, (int*)nullptr);
+                         skip_thr, (const int*)nullptr, (float*)nullptr, (int*)nullptr, 0, (float*)nullptr, (int*)nullptr, 0);
       const int n_blk = (ncols + 31) / 32, per_wg = 4 * p.apply_tiles;     // 32-column blocks, 4 waves per workgroup
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_blk + per_wg - 1) / per_wg, nz), dim3(256), 0, st,
                          aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R, w.skip + (size_t)z0 * p.npairs);
@@ -1080,13 +1093,22 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
   // Two-level scheme (wm_ref_hier.inc): the same rotations with the rows streamed 3 times per SUPER-step.
   // WM_RF_HIER=0 / 1 forces the flat tournament / the two-level scheme (read per call, so that a test can hold the two against each other);
   // WM_RF_HIER_SB = blocks per super-block (2, 4 or 6).
-  // Default: from HIER_MIN_PLANES planes per call on (measured crossover on 1080p planes, profiles/r04_hier_crossover.log: 20 planes
-  // 144 / 144 frames/s, 24: 141 / 158, 48: 142 / 178 flat / two-level; a small batch is latency-bound and the flat step's chain
-  // gram - inner - apply is the shorter one: 2 planes 20.9 / 26.5 ms).
-  const bool hier = getenv("WM_RF_HIER") ? atoi(getenv("WM_RF_HIER")) != 0 : p.B >= HIER_MIN_PLANES;
+  // Default (measured on 1080p planes, profiles/r04_hier_crossover.log): with the split-f16 kernels - uint8 planes, i.e. every
+  // embed / sigma / extract / detect call - the two-level scheme wins from 4 planes per call on (2: 44 / 44, 4: 72 / 79, 8: 104 / 128,
+  // 16: 138 / 180, 64: 140 / 242 frames/s flat / two-level) and is used from HIER_MIN_PLANES_F16 = 3; with the f32 kernels (float
+  // inputs: the watermark-side SVD, the completion) only from HIER_MIN_PLANES = 20 (2 planes: 20.9 / 26.5 ms - a small batch is
+  // latency-bound and the flat step's chain gram - inner - apply is the shorter one).
+  const int f16_env = getenv("WM_RF_HIER_F16") ? atoi(getenv("WM_RF_HIER_F16")) : HIER_F16_DEFAULT;     // bit 0: Gram, bit 1: rotation products
+  const bool f16_ok = use == JR_SIGMA || use == JR_EMBED;     // rows of uint8 planes: |entries| <= 255 sqrt(L) < 65 504 under orthogonal rotations
+  const bool gram_f16 = (f16_env & 1) && f16_ok, apply_f16 = (f16_env & 2) && f16_ok;
+  const bool hier = getenv("WM_RF_HIER") ? atoi(getenv("WM_RF_HIER")) != 0
+                                         : p.B >= ((gram_f16 && apply_f16) ? HIER_MIN_PLANES_F16 : HIER_MIN_PLANES);
   const HierTab* ht = nullptr;
   HierWs hw{};
-  const int hdbg = getenv("WM_RF_HDBG") ? atoi(getenv("WM_RF_HDBG")) : 0;     // timing experiments only (results are wrong): see the kernels
+  const int hdbg = getenv("WM_RF_HDBG") ? atoi(getenv("WM_RF_HDBG")) : 0;
+  // Gram tiles on the f16 matrix pipe with split operands (k_hgram_h; WM_RF_HIER_F16=0: the f32 form).  Row entries are bounded
+  // by 255 sqrt(L): beyond L = 65 536 (never a plane) f16 would overflow, and float inputs (the watermark-side SVD of a DCT
+  // plane, the completion's random vectors) have no such bound - those uses keep the f32 kernel.
   if (hier) {
     int sb = 6;
     if (const char* e = getenv("WM_RF_HIER_SB")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 6) sb = v; }
@@ -1095,6 +1117,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     static bool attr_set = false;
     if (!attr_set) {
       WM_HIP(hipFuncSetAttribute((const void*)k_happly, hipFuncAttributeMaxDynamicSharedMemorySize, HN * 65 * 4));
+      WM_HIP(hipFuncSetAttribute((const void*)k_happly_h, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * HA_CP * 2));
       attr_set = true;
     }
   }
@@ -1115,8 +1138,12 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     const int nchunk = (p.M + HG_KC - 1) / HG_KC;
     const int KS = hier_ks(nsp, nz, npmax, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
     const int ngrp = nsp * KS * nz;               // (super-pair, split, plane) groups of npmax workgroups, dealt over the XCDs
-    hipLaunchKernelGGL(k_hgram, dim3(((ngrp + 7) / 8) * 8 * npmax), dim3(512), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
-                       par, KS, cps, npmax, nz, hdbg);
+    if (gram_f16)
+      hipLaunchKernelGGL(k_hgram_h, dim3(((ngrp + 7) / 8) * 8 * npmax), dim3(512), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
+                         par, KS, cps, npmax, nz);
+    else
+      hipLaunchKernelGGL(k_hgram, dim3(((ngrp + 7) / 8) * 8 * npmax), dim3(512), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
+                         par, KS, cps, npmax, nz, hdbg);
     hipLaunchKernelGGL(k_hreduce, dim3(HSB * (HSB + 1) / 2, nsp, nz), dim3(256), 0, st, par, sup, nsp, KS, Gs, anyrot);
     constexpr int NG = HU * (HU - 1) / 2;
     const int T = ht->T[s1];
@@ -1125,13 +1152,17 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
       const int* un = un0 + (size_t)t * nsp * HU;
       hipLaunchKernelGGL(k_rf_inner, dim3(nsp * HU, 1, nz), dim3(INNER_NT), 0, st, (const float*)nullptr, 0, R, w.maxcos + z0,
                          w.floor2 + z0, (s1 == 0 && t == 0) ? 0 : 1, skip, skip_thr, un, Gs, anyrot, nsp, Rpk + t * rpk_stage,
-                         skipT + t * skip_stage);
+                         skipT + t * skip_stage, apply_f16 ? 1 : 0);
       if (t + 1 < T)                               // nothing reads G_s after the last stage
         hipLaunchKernelGGL(k_hupdate, dim3(NG, nsp, nz), dim3(256), 0, st, un, sup, nsp, R, skip, Gs);
     }
     const int ntask = nsp * nz * ((ncols + 63) / 64);
-    hipLaunchKernelGGL(k_happly, dim3(8 * ((ntask + 7) / 8)), dim3(64 * ht->nmax), (size_t)n32 * 65 * 4, st, aug, p.aug_ps, p.ld, ncols,
-                       sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot, hdbg >> 4);
+    if (apply_f16)
+      hipLaunchKernelGGL(k_happly_h, dim3(8 * ((ntask + 7) / 8)), dim3(64 * ht->nmax), (size_t)2 * 64 * HA_CP * 2, st, aug, p.aug_ps, p.ld,
+                         ncols, sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot);
+    else
+      hipLaunchKernelGGL(k_happly, dim3(8 * ((ntask + 7) / 8)), dim3(64 * ht->nmax), (size_t)n32 * 65 * 4, st, aug, p.aug_ps, p.ld, ncols,
+                         sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot, hdbg >> 4);
   };
   while (!done && sweep < MAX_SWEEPS) {
     WM_HIP(hipMemsetAsync(w.maxcos, 0, (size_t)p.B * sizeof(unsigned), ctx->stream));

@@ -53,9 +53,13 @@ def _planes(B, H, W, seed=5):
     return planes
 
 
+@pytest.mark.parametrize("f16", [3, 0, 1])
 @pytest.mark.parametrize("sb", [6, 4, 2])
 @pytest.mark.parametrize("B,H,W", [(1, 64, 96), (2, 128, 200), (1, 200, 136), (3, 320, 480), (1, 448, 448), (1, 832, 900)])
-def test_two_level_against_lapack_and_the_flat_tournament(gpu_ctx, monkeypatch, sb, B, H, W):
+def test_two_level_against_lapack_and_the_flat_tournament(gpu_ctx, monkeypatch, sb, B, H, W, f16):
+    """f16 = 3: Gram tiles and rotation products from split-f16 operands on the f16 matrix pipe (the default for uint8 planes),
+    1: the Gram tiles only, 0: the f32 kernels - the same bars for all three."""
+    monkeypatch.setenv("WM_RF_HIER_F16", str(f16))
     planes = _planes(B, H, W)
     ref = np.stack([np.linalg.svd(p.astype(np.float64), compute_uv=False) for p in planes])
     monkeypatch.setenv("WM_RF_HIER", "0")
@@ -87,12 +91,42 @@ def test_two_level_is_deterministic_and_batch_independent(gpu_ctx):
 
 
 def test_default_scheme_follows_the_batch_size(gpu_ctx, monkeypatch):
+    """uint8 planes (split-f16 kernels apply): two-level from 3 planes per call on; float inputs (the watermark-side SVD keeps
+    the f32 kernels): from 20."""
     monkeypatch.delenv("WM_RF_HIER", raising=False)
+    monkeypatch.delenv("WM_RF_HIER_F16", raising=False)
     small = _planes(2, 64, 96)
     gpu_ctx.ref_sigma_planes(small)
     assert gpu_ctx.ref_last_flops()[1] is False
-    big = np.repeat(_planes(1, 64, 96), 24, axis=0)
+    big = np.repeat(_planes(1, 64, 96), 5, axis=0)
     s = gpu_ctx.ref_sigma_planes(big)
     assert gpu_ctx.ref_last_flops()[1] is True
     ref = np.linalg.svd(big[0].astype(np.float64), compute_uv=False)
     assert np.max(np.abs(s - ref[None, :])) / ref[0] < 2e-6
+    wm = np.random.default_rng(3).integers(0, 256, (3, 64, 96)).astype(np.float32)
+    gpu_ctx.ref_svd_planes(wm, apply_dct=True)
+    assert gpu_ctx.ref_last_flops()[1] is False
+
+
+def test_split_f16_keeps_the_embed_within_the_bars_on_extreme_planes(gpu_ctx, monkeypatch):
+    """The split-f16 products see rows whose entries reach 255 sqrt(L) (a saturated plane: sigma_1 = 255 sqrt(H W)) and rows of
+    tiny magnitude (a plane of zeros and ones): the singular values stay within the suite's bar of float64 LAPACK and the embed
+    within 1 LSB of the f32 kernels' result."""
+    rng = np.random.default_rng(2)
+    H, W = 256, 416
+    planes = np.stack([np.full((H, W), 255, np.uint8), rng.integers(0, 2, (H, W)).astype(np.uint8),
+                       rng.integers(250, 256, (H, W)).astype(np.uint8), rng.integers(0, 256, (H, W)).astype(np.uint8)])
+    planes[0, ::7, ::5] = 254                                   # (not exactly rank 1)
+    ref = np.stack([np.linalg.svd(p.astype(np.float64), compute_uv=False) for p in planes])
+    sw = np.linspace(300.0, 1.0, H).astype(np.float32)
+    out = {}
+    for f16 in (0, 3):
+        monkeypatch.setenv("WM_RF_HIER_F16", str(f16))
+        s = gpu_ctx.ref_sigma_planes(planes)
+        assert np.max(np.abs(s - ref) / ref[:, :1]) < 2e-6, f16
+        out[f16] = gpu_ctx.ref_embed_planes(planes, sw, 0.15, int(0.6 * H))
+    # plane 0 is rank-deficient (2 of 256 directions): its missing ranks go along an arbitrary orthonormal completion that
+    # depends on the rotated rows' last bits - like LAPACK's - so pixels are only comparable on the full-rank planes
+    d = np.abs(out[0][0][1:].astype(int) - out[3][0][1:].astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+    assert np.max(np.abs(out[0][1] - out[3][1]) / ref[:, :1]) < 1e-6
