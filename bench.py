@@ -424,6 +424,11 @@ def fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup,
     # 128 x 128 Gram tiles + one (<= 384)^2 rotation per super-pair and super-step + the stage updates
     flops_issued, two_level = ctx.ref_last_flops()
     achieved = flops_issued / t_embed / 1e12
+    # With uint8 planes the two-level scheme issues its Gram and rotation products on the f16 matrix pipe as three split products
+    # each (hi hi + hi lo + lo hi): `achieved` stays the f32-EQUIVALENT flop count (what an f32 implementation of the same schedule
+    # would issue) against the f32 matrix peak, which is the figure comparable with earlier rounds; the f16 pipe itself sees 3 x
+    # those flops against its own ~2.5 PFLOP/s dense peak
+    split_f16 = two_level and os.environ.get("WM_RF_HIER_F16", "3") not in ("0",)
     # SURVEY 8(d)'s algorithmic count of what the embed computes per plane: one thin SVD, 6 M N^2 + 20 N^3 (M long, N short side)
     alg_flops = F * (6.0 * M * L * L + 20.0 * float(L) ** 3)
     achieved_alg = alg_flops / t_embed / 1e12
@@ -452,8 +457,12 @@ def fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup,
                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                         "achieved_algorithmic": achieved_alg, "frac_algorithmic": achieved_alg / MFMA_F32_PEAK_TFLOPS,
                         "algorithmic_flops_per_launch": alg_flops,
-                        "kernel": ("two-level block Jacobi (k_hgram + k_happly + k_hupdate products)" if two_level else
+                        "kernel": ("two-level block Jacobi (k_hgram_h + k_happly_h + k_hupdate products)" if two_level else
                                    "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)"),
+                        "matrix_pipe": ("f16, split operands: 3 x v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 tile product (f32-class accuracy)"
+                                        if split_f16 else "f32: v_mfma_f32_32x32x2_f32"),
+                        "f16_pipe_flops_issued_TFLOPs": (3.0 * achieved if split_f16 else None),
+                        "f16_pipe_frac_of_2500_TFLOPs": (3.0 * achieved / 2500.0 if split_f16 else None),
                         "note": f"{sweeps_e} sweeps over {nbk} blocks of 32 rows; `achieved` / `frac` count the Jacobi's OWN issued matrix-core "
                                 f"flops (wm_ref_last_flops) over the whole embed call (the per-pair inner solve and the finalisation GEMMs "
                                 f"are in the time, not in the flops); `frac_algorithmic` prices the same time against SURVEY 8(d)'s thin-SVD "
@@ -613,7 +622,7 @@ def live_pmc_fullframe(a, timeout_s=240):
     env = dict(os.environ, TMPDIR="/tmp", WM_BENCH_NO_V16="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    jac = ("k_rf_gram", "k_rf_inner", "k_rf_apply", "k_hgram", "k_hreduce", "k_hupdate", "k_hpack", "k_happly")
+    jac = ("k_rf_gram", "k_rf_inner", "k_rf_apply", "k_hgram_h", "k_happly_h", "k_hgram", "k_hreduce", "k_hupdate", "k_happly")
     tot, per_kernel, calls = {}, {}, 0
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
