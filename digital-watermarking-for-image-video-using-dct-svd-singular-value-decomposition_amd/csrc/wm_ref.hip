@@ -577,8 +577,9 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 2 * INNER_NB; ++j) {
       const int r = kr + INNER_KR * j;
-      out[r * RP + k2] = ri[j];
-      out[r * RP + RB + k2] = rj[j];
+      // (two-level scheme: Rout in the packed order as well - k_hupdate takes its MFMA operands straight from it)
+      out[h_units ? pk_index(r, k2) : r * RP + k2] = ri[j];
+      out[h_units ? pk_index(r, RB + k2) : r * RP + RB + k2] = rj[j];
       if (rpk) { put_r(r, k2, ri[j]); put_r(r, RB + k2, rj[j]); }
     }
     if (h_units) writeback(gbuf0);             // 32 steps: the result is back in buffer 0, behind the last step's barrier
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   st3 = __builtin_amdgcn_s_memtime();
 #endif
   for (int e = t; e < RP * RP; e += INNER_NT) {
-    out[e] = R[e >> 6][e & 63];
+    out[h_units ? pk_index(e >> 6, e & 63) : e] = R[e >> 6][e & 63];
     if (rpk) put_r(e >> 6, e & 63, R[e >> 6][e & 63]);
   }
   if (h_units) writeback(&G[0][0]);
