@@ -291,3 +291,190 @@ def detect_watermark_video(stego_video_path: str, metadata_path: str, thresh: fl
         ctx.close()
     mean = float(scores.mean()) if scores.size else 0.0
     return bool(mean >= thresh), mean, scores
+
+
+# ---------------------------------------------------------------------------
+# colour video (names of the reference's bytecode-only ``color_video_dct_svd`` module: ``embed_watermark_video_color`` /
+# ``extract_watermark_video_color``; its source is not in the tree, so the SHAPE is the colour image embed of single:121-166
+# put into the luma loop above: the colour watermark's B, G, R planes are decomposed ONCE, every marked frame's B, G, R planes
+# are embedded with them, per-frame host singular values per channel go to the metadata, extraction averages over the marked
+# frames per channel).  Container: 8-bit 4:4:4 ``.y4m`` (planes Y, Cb, Cr); the frames pass through OpenCV's fixed-point
+# YCrCb <-> BGR conversion on the device (``wm_color_u8``) on the way in and out, so - like any YUV container - the stored
+# stego differs from the embedded BGR planes by that conversion's rounding (a grey level or two per channel).  No audio remux.
+# ---------------------------------------------------------------------------
+def _frame_to_bgr_planes(ctx: hostapi.Context, y: np.ndarray, chroma: np.ndarray, H: int, W: int) -> np.ndarray:
+    cb = chroma[:H * W].reshape(H, W); cr = chroma[H * W:].reshape(H, W)
+    bgr = ctx.color("ycrcb2bgr", np.ascontiguousarray(np.stack([y, cr, cb], axis=-1)))       # OpenCV order: Y, Cr, Cb
+    return np.ascontiguousarray(np.moveaxis(bgr, -1, 0))                                       # [3, H, W]: B, G, R
+
+
+def _bgr_planes_to_frame(ctx: hostapi.Context, planes: np.ndarray):
+    ycc = ctx.color("bgr2ycrcb", np.ascontiguousarray(np.moveaxis(planes, 0, -1)))
+    return np.ascontiguousarray(ycc[..., 0]), np.ascontiguousarray(ycc[..., 2]), np.ascontiguousarray(ycc[..., 1])   # Y, Cb, Cr
+
+
+def prepare_watermark_color(ctx: hostapi.Context, wm_bgr: np.ndarray, H: int, W: int, key: bytes, tile: Optional[int] = TILE):
+    """resize -> B, G, R planes -> ONE keyed pixel shuffle for all three (single:124-126) -> their three decompositions in one
+    batched call.  Returns (Uw [3, ...], Sw [3, ...], Vwt [3, ...], idx)."""
+    wm = hg.resize_area(wm_bgr, W, H)
+    idx = hg.permutation_index(H, W, key)
+    planes = ctx.permute_planes(np.ascontiguousarray(np.moveaxis(wm, -1, 0)), idx)
+    if tile:
+        Uw, Sw, Vwt = ctx.svd_tiles(planes)
+    else:
+        Uw, Sw, Vwt = ctx.ref_svd_planes(planes.astype(np.float32), apply_dct=True)
+    return Uw, Sw, Vwt, idx
+
+
+_CH = "bgr"
+
+
+def embed_frames_color(ctx: hostapi.Context, planes: np.ndarray, Sw: np.ndarray, alpha: float, K: int = 8, batch: int = 8,
+                       tile: Optional[int] = TILE):
+    """planes uint8 [n, 3, H, W] (B, G, R of n frames), Sw [3, ...] -> (stego [n, 3, H, W], [Sb, Sg, Sr]): channel c of every
+    frame gets the watermark's channel c (single:139-152); one set of launches per channel and batch."""
+    st = np.empty_like(planes)
+    sc = []
+    for ch in range(3):
+        s, c = embed_frames(ctx, np.ascontiguousarray(planes[:, ch]), Sw[ch], alpha, K, batch, tile)
+        st[:, ch] = s; sc.append(c)
+    return st, sc
+
+
+def embed_watermark_video_color(host_video_path: str, watermark_path: str, output_video_path: str,
+                                metadata_path: str, alpha: float = 0.1, frame_interval: int = 1, *,
+                                password: str = "", nonce: Optional[bytes] = None, kfrac: float = hg.K_FRAC_DEFAULT,
+                                k_floor: int = 8, batch: int = 8, device: int = 0, tile: Optional[int] = TILE):
+    """Embed a colour watermark into the B, G, R planes of every ``frame_interval``-th frame of a 4:4:4 .y4m video.
+    Returns (output_video_path, metadata_path, mean PSNR of the marked frames' BGR planes)."""
+    if tile not in (TILE, None):
+        raise ValueError("tile must be 8 or None")
+    if not password:
+        raise ValueError("Vui lòng nhập mật khẩu để nhúng.")
+    ctx = hostapi.Context(device)
+    vid = Y4M(host_video_path)
+    try:
+        if vid.chroma != "444":
+            raise ValueError("embed_watermark_video_color needs an 8-bit 4:4:4 .y4m (C444): per-channel embedding needs full-resolution chroma")
+        H, W = vid.H, vid.W
+        if nonce is None:
+            nonce = os.urandom(8)
+        key = hg.derive_key(password, nonce)
+        Uw, Sw, Vwt, _ = prepare_watermark_color(ctx, hg.read_image_bgr(watermark_path), H, W, key, tile)
+        K = _k_of(tile, kfrac, k_floor, H, W)
+        sc_all = [[], [], []]
+        psnrs, n_frames = [], 0
+        with open(output_video_path, "wb") as out:
+            out.write(vid.header_line)
+            pend = []          # (frame_line, y, chroma, marked)
+
+            def flush():
+                marked = [p for p in pend if p[3]]
+                if marked:
+                    planes = np.stack([_frame_to_bgr_planes(ctx, p[1], p[2], H, W) for p in marked])     # [n, 3, H, W]
+                    st, sc = embed_frames_color(ctx, planes, Sw, alpha, K, batch, tile)
+                    for ch in range(3):
+                        sc_all[ch].append(sc[ch])
+                    psnrs.extend(hg.psnr(planes[i], st[i]) for i in range(len(marked)))
+                j = 0
+                for line, y, chroma, is_marked in pend:
+                    if is_marked:
+                        yy, cb, cr = _bgr_planes_to_frame(ctx, st[j]); j += 1
+                        out.write(line); out.write(yy.tobytes()); out.write(cb.tobytes()); out.write(cr.tobytes())
+                    else:
+                        out.write(line); out.write(y.tobytes()); out.write(chroma.tobytes())
+                pend.clear()
+
+            for line, y, chroma in vid:
+                pend.append((line, y.copy(), chroma.copy(), n_frames % max(1, frame_interval) == 0))
+                n_frames += 1
+                if len(pend) >= batch * max(1, frame_interval):
+                    flush()
+            flush()
+        empty = np.zeros((0, H // TILE, W // TILE, 8) if tile else (0, min(H, W)), np.float32)
+        S = [np.concatenate(sc_all[ch]) if sc_all[ch] else empty for ch in range(3)]
+        digest = hg.hmac_digest(key, S + [Uw[ch] for ch in range(3)] + [Vwt[ch] for ch in range(3)])     # the coverage of single:160-161
+        meta = dict(mode="video_color", payload_type="image", shape=np.array((H, W)), alpha=float(alpha), kfrac=float(kfrac),
+                    frame_interval=np.int32(frame_interval), n_frames=np.int32(n_frames), tile=np.int32(tile or 0),
+                    k_floor=np.int32(k_floor), nonce=np.frombuffer(nonce, dtype=np.uint8), digest=np.frombuffer(digest, dtype=np.uint8))
+        for ch, n in enumerate(_CH):                     # the colour image meta's key names (single:157-166)
+            meta["S" + n] = S[ch]; meta["UW" + n] = Uw[ch]; meta["VW" + n + "t"] = Vwt[ch]; meta["SW" + n] = Sw[ch]
+        np.savez(metadata_path, **meta)
+        return output_video_path, metadata_path, float(np.mean(psnrs)) if psnrs else 99.0
+    finally:
+        vid.close(); ctx.close()
+
+
+def _load_video_meta_color(metadata_path: str):
+    data = np.load(metadata_path, allow_pickle=False)
+    if str(data["mode"]) != "video_color":
+        raise ValueError("metadata was not written by embed_watermark_video_color")
+    return data
+
+
+def _marked_bgr(ctx: hostapi.Context, stego_video_path: str, data) -> np.ndarray:
+    vid = Y4M(stego_video_path)
+    try:
+        if vid.chroma != "444":
+            raise ValueError("a colour-watermarked video is 4:4:4")
+        fi = int(data["frame_interval"]); n = data["Sb"].shape[0]
+        H, W = vid.H, vid.W
+        out = []
+        for i, (_, y, chroma) in enumerate(vid):
+            if i % max(1, fi) == 0 and len(out) < n:
+                out.append(_frame_to_bgr_planes(ctx, y, chroma, H, W))
+    finally:
+        vid.close()
+    if len(out) < n:
+        raise ValueError("video has fewer marked frames than the metadata")
+    return np.stack(out) if out else np.zeros((0, 3) + tuple(map(int, data["shape"])), np.uint8)
+
+
+def extract_watermark_video_color(stego_video_path: str, metadata_path: str, output_image_path: str, password: str,
+                                  normalize: bool = True, *, batch: int = 8, device: int = 0) -> str:
+    """Averaged multi-frame extraction per channel -> colour watermark image (PNG)."""
+    if not password:
+        raise ValueError("Vui lòng nhập mật khẩu để giải trích.")
+    data = _load_video_meta_color(metadata_path)
+    H, W = map(int, data["shape"])
+    nonce = bytes(bytearray(data["nonce"].astype(np.uint8).tolist()))
+    key = hg.derive_key(password, nonce)
+    parts = [data["S" + n] for n in _CH] + [data["UW" + n] for n in _CH] + [data["VW" + n + "t"] for n in _CH]
+    if not hg.digests_equal(hg.hmac_digest(key, parts), bytes(bytearray(data["digest"].astype(np.uint8).tolist()))):
+        raise ValueError("Sai mật khẩu hoặc meta không khớp.")
+    ctx = hostapi.Context(device)
+    try:
+        planes = _marked_bgr(ctx, stego_video_path, data)
+        tile = _meta_tile(data)
+        K = _k_of(tile, float(data["kfrac"]), int(data["k_floor"]), H, W)
+        idx = hg.permutation_index(H, W, key)
+        chans = []
+        for ch, n in enumerate(_CH):
+            w_s = extract_frames_mean(ctx, np.ascontiguousarray(planes[:, ch]), data["S" + n], data["UW" + n], data["VW" + n + "t"],
+                                      float(data["alpha"]), K, batch, tile)
+            chans.append(ctx.unpermute_normalize_u8(w_s, idx, normalize))                    # single:265-271 per channel
+        img = np.stack(chans, axis=-1)
+    finally:
+        ctx.close()
+    if not output_image_path.lower().endswith(".png"):
+        output_image_path = os.path.splitext(output_image_path)[0] + "_wm.png"
+    if not hg.write_png(output_image_path, img, 1):
+        raise IOError("Ghi watermark thất bại.")
+    return output_image_path
+
+
+def detect_watermark_video_color(stego_video_path: str, metadata_path: str, thresh: float = 0.6, *,
+                                 batch: int = 8, device: int = 0):
+    """(bool, mean score, per-frame scores): a frame's score is the mean of its three channels' NC (single:317)."""
+    data = _load_video_meta_color(metadata_path)
+    ctx = hostapi.Context(device)
+    try:
+        planes = _marked_bgr(ctx, stego_video_path, data)
+        tile = _meta_tile(data)
+        per_ch = [detect_frames(ctx, np.ascontiguousarray(planes[:, ch]), data["S" + n], data["SW" + n], float(data["alpha"]), batch, tile)
+                  for ch, n in enumerate(_CH)]
+    finally:
+        ctx.close()
+    scores = (per_ch[0] + per_ch[1] + per_ch[2]) / 3.0
+    mean = float(scores.mean()) if scores.size else 0.0
+    return bool(mean >= thresh), mean, scores

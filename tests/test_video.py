@@ -167,3 +167,92 @@ def test_video_parameter_sweep(tmp_path, gpu_ctx):
         assert not ok0, c
         w = v.extract_watermark_video(outp, meta, str(sub / "w.png"), password="pw", batch=c["batch"])
         assert hg.read_image_bgr(w).shape[:2] == (c["H"], c["W"])
+
+
+def _video444(tmp_path, n=5, H=64, W=96, seed=8):
+    rng = np.random.default_rng(seed)
+    # a smooth colourful clip (random chroma would leave the BGR gamut and be clipped by the conversion)
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    for i in range(n):
+        b = 90 + 60 * np.sin((xx + 3 * i) / 11.0) + rng.normal(0, 6, (H, W))
+        g = 120 + 50 * np.cos((yy - 2 * i) / 7.0) + rng.normal(0, 6, (H, W))
+        r = 100 + 40 * np.sin((xx + yy) / 13.0) + rng.normal(0, 6, (H, W))
+        frames.append(np.clip(np.stack([b, g, r], axis=-1), 0, 255).astype(np.uint8))
+    ycc = [o.bgr_to_ycrcb(f) for f in frames]
+    ys = np.stack([f[..., 0] for f in ycc])
+    chroma = np.stack([np.concatenate([f[..., 2].ravel(), f[..., 1].ravel()]) for f in ycc])     # Cb plane, then Cr plane
+    v = importlib.import_module(PKG_NAME + ".video")
+    p = str(tmp_path / "in444.y4m")
+    v.write_y4m(p, ys, chroma, chroma_tag="444")
+    return v, p, ys, chroma
+
+
+def _bgr_of(y, chroma):
+    H, W = y.shape
+    cb = chroma[:H * W].reshape(H, W); cr = chroma[H * W:].reshape(H, W)
+    return o.ycrcb_to_bgr(np.stack([y, cr, cb], axis=-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [8, None])
+def test_video_color_444(tmp_path, gpu_ctx, tile):
+    """Colour video on a 4:4:4 .y4m: every marked frame's B, G, R planes carry the colour watermark's B, G, R planes (decomposed
+    once), held per plane against the oracle; the file round trip goes through the YCrCb conversion and is checked through it."""
+    v, p, ys, chroma = _video444(tmp_path)
+    hg = importlib.import_module(PKG_NAME + ".hostglue")
+    wm = np.random.default_rng(5).integers(0, 256, (16, 24, 3), dtype=np.uint8)
+    wp = str(tmp_path / "wmc.png"); assert hg.write_png(wp, wm)
+    H, W = 64, 96
+    key = o.derive_key("pw", bytes(8)); idx = o.permutation(H, W, o.rng_from_key(key))
+    wm_r = o.resize_area(wm, W, H)
+    w_s = [o.permute(wm_r[..., c].astype(np.float32), idx) for c in range(3)]
+    wm_svd = [o.watermark_decompose(w, tile) for w in w_s]
+    # array level: per plane against the oracle, bit-level bars of the grey path
+    Uw, Sw, Vwt, idx_g = v.prepare_watermark_color(gpu_ctx, wm, H, W, key, tile)
+    assert np.array_equal(idx_g, idx)
+    for c in range(3):
+        assert np.max(np.abs(Sw[c] - wm_svd[c][1])) / np.max(wm_svd[c][1]) < 1e-5
+    bgr = np.stack([np.moveaxis(_bgr_of(ys[i], chroma[i]), -1, 0) for i in range(5)])               # [5, 3, H, W]
+    K = 8 if tile else int(0.6 * 64)
+    st, sc = v.embed_frames_color(gpu_ctx, bgr, Sw, 0.15, K, batch=2, tile=tile)
+    for i in range(5):
+        for c in range(3):
+            ref = o.embed_plane(bgr[i, c].astype(np.float32), w_s[c], 0.15, 0.6, tile, wm_svd=wm_svd[c] if tile else None)
+            assert np.abs(st[i, c].astype(int) - ref["stego"].astype(int)).max() <= 1
+            assert np.mean(st[i, c] != ref["stego"]) < 5e-3
+            assert np.max(np.abs(sc[c][i] - ref["Sc"])) / np.max(ref["Sc"]) < 1e-4
+    # file level
+    outp, meta, ps = v.embed_watermark_video_color(p, wp, str(tmp_path / "outc.y4m"), str(tmp_path / "vmc.npz"), alpha=0.15,
+                                                   frame_interval=2, password="pw", nonce=bytes(8), batch=2, tile=tile)
+    assert 15 < ps < 60
+    data = np.load(meta, allow_pickle=False)
+    assert str(data["mode"]) == "video_color" and int(data["n_frames"]) == 5
+    for n in "bgr":
+        assert data["S" + n].shape[0] == 3 and np.array_equal(data["S" + n], sc["bgr".index(n)][::2])
+    vid = v.Y4M(outp); got = [(y.copy(), c.copy()) for _, y, c in vid]; vid.close()
+    assert vid.chroma == "444" and len(got) == 5
+    for i, (y, c) in enumerate(got):
+        if i % 2:
+            assert np.array_equal(y, ys[i]) and np.array_equal(c, chroma[i])                        # unmarked frames untouched
+        else:
+            want = o.bgr_to_ycrcb(np.moveaxis(st[i], 0, -1))                                        # the container's conversion
+            assert np.array_equal(y, want[..., 0])
+            assert np.array_equal(c, np.concatenate([want[..., 2].ravel(), want[..., 1].ravel()]))
+    ok, mean, scores = v.detect_watermark_video_color(outp, meta)
+    assert ok and mean > 0.9 and scores.shape == (3,)
+    ok0, mean0, _ = v.detect_watermark_video_color(p, meta)
+    assert not ok0 and mean0 < mean
+    wout = v.extract_watermark_video_color(outp, meta, str(tmp_path / "wc.png"), password="pw")
+    ex = hg.read_image_bgr(wout)
+    assert ex.shape == (H, W, 3)
+    for c in range(3):
+        assert np.corrcoef(ex[..., c].ravel().astype(float), wm_r[..., c].ravel().astype(float))[0, 1] > 0.6
+    with pytest.raises(ValueError, match="Sai mật khẩu"):
+        v.extract_watermark_video_color(outp, meta, str(tmp_path / "x.png"), password="nope")
+    # containers without full-resolution chroma are refused, and the grey reader refuses colour metadata
+    v2, p420, _, _ = _video(tmp_path)
+    with pytest.raises(ValueError, match="4:4:4"):
+        v.embed_watermark_video_color(p420, wp, str(tmp_path / "o2.y4m"), str(tmp_path / "m2.npz"), password="pw")
+    with pytest.raises(ValueError):
+        v.detect_watermark_video(outp, meta)
