@@ -49,7 +49,6 @@ constexpr float SKIP_FRACTION = 0.25f;    // a block pair below this fraction of
 constexpr double RESIDUE_RHO = 10.0;      // |A0 b_i^T| / |b_i|^2 above this: b_i is not a singular direction at all
 constexpr double T_SWITCH = 200.0;        // |A0 b_i^T| / |b_i| is used for s_i >= T_SWITCH * (residual cosine) * s_max
 constexpr int HIER_F16_DEFAULT = 3;         // two-level scheme, split-f16 operands on the f16 matrix pipe: bit 0 Gram tiles (k_hgram_h), bit 1 rotation products (k_happly_h); WM_RF_HIER_F16 overrides
-constexpr bool HIER_STRIP32_DEFAULT = false;
 constexpr int HIER_MIN_PLANES = 20;         // ... with the f32 kernels
 constexpr int HIER_MIN_PLANES_F16 = 3;      // planes per call from which the two-level scheme is the default when its split-f16 kernels apply        // planes per call from which the two-level scheme (wm_ref_hier.inc) is the default
 constexpr int DEFAULT_QUEUES = 2;         // plane groups of a batched Jacobi, each on its own HIP queue
@@ -1108,7 +1107,6 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
   const HierTab* ht = nullptr;
   HierWs hw{};
   const int hdbg = getenv("WM_RF_HDBG") ? atoi(getenv("WM_RF_HDBG")) : 0;
-  const bool strip32 = getenv("WM_RF_HIER_SW") ? atoi(getenv("WM_RF_HIER_SW")) == 32 : HIER_STRIP32_DEFAULT;   // k_happly_h: 32- instead of 64-column strips
   // Gram tiles on the f16 matrix pipe with split operands (k_hgram_h; WM_RF_HIER_F16=0: the f32 form).  Row entries are bounded
   // by 255 sqrt(L): beyond L = 65 536 (never a plane) f16 would overflow, and float inputs (the watermark-side SVD of a DCT
   // plane, the completion's random vectors) have no such bound - those uses keep the f32 kernel.
@@ -1121,7 +1119,6 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     if (!attr_set) {
       WM_HIP(hipFuncSetAttribute((const void*)k_happly, hipFuncAttributeMaxDynamicSharedMemorySize, HN * 65 * 4));
       WM_HIP(hipFuncSetAttribute((const void*)k_happly_h<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * HA_CP * 2));
-      WM_HIP(hipFuncSetAttribute((const void*)k_happly_h<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * HA_CP * 2));
       attr_set = true;
     }
   }
@@ -1161,13 +1158,9 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
         hipLaunchKernelGGL(k_hupdate, dim3(NG, nsp, nz), dim3(256), 0, st, un, sup, nsp, R, skip, Gs);
     }
     const int ntask = nsp * nz * ((ncols + 63) / 64);
-    if (apply_f16 && strip32) {
-      const int nt32 = nsp * nz * ((ncols + 31) / 32);
-      hipLaunchKernelGGL((k_happly_h<32>), dim3(8 * ((nt32 + 7) / 8)), dim3(64 * ht->nmax), (size_t)2 * 32 * HA_CP * 2, st, aug, p.aug_ps, p.ld,
-                         ncols, sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot);
-    } else if (apply_f16)
+    if (apply_f16)
       hipLaunchKernelGGL((k_happly_h<64>), dim3(8 * ((ntask + 7) / 8)), dim3(64 * ht->nmax), (size_t)2 * 64 * HA_CP * 2, st, aug, p.aug_ps, p.ld,
-                         ncols, sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot);
+                         ncols, sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot, hdbg >> 4);
     else
       hipLaunchKernelGGL(k_happly, dim3(8 * ((ntask + 7) / 8)), dim3(64 * ht->nmax), (size_t)n32 * 65 * 4, st, aug, p.aug_ps, p.ld, ncols,
                          sup, nsp, nz, un0, T, Rpk, skipT, rpk_stage, skip_stage, anyrot, hdbg >> 4);
