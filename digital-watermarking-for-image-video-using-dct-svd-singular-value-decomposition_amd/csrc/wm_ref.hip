@@ -16,6 +16,8 @@
 //  * embed is V-free: Yw = Y + Q diag(alpha*sw_rank(i) / sigma_i) B.
 // DCT-domain factors (watermark side / extract) use plain tiled SGEMMs with the
 // DCT basis matrices.
+#include <chrono>
+#include <thread>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1469,11 +1471,22 @@ int ref_complete_plane(wm_ctx* ctx, const RefPlan& p, const RefWs& w, int z, con
 // d_yw [B][L][M] and d_t [B][L][Lp] are workspace.
 int ref_embed_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t* d_in, uint8_t* d_out, float* d_ywout,
                    size_t row_stride, size_t plane_stride, float* d_yw, float* d_t, const float* sigma_w,
-                   size_t sigma_w_plane_stride, float* sigma_c, float alpha, int K) {
+                   size_t sigma_w_plane_stride, float* sigma_c, float alpha, int K, const int* sigma_w_ready = nullptr) {
   const size_t yw_ps = (size_t)p.L * p.M;
   RefSpectrum sp;
   // Yw starts as A itself (exactly the pixels): ref_decompose leaves that copy in d_yw
   WM_TRY(ref_decompose(ctx, p, w, d_in, row_stride, plane_stride, d_yw, d_t, JR_EMBED, sp));
+  // sigma_w is first read here, after the host planes' decomposition (the long part of the call): a caller that is still
+  // computing it - the watermark's own SVD on another context and thread, single:172-173's two independent statements -
+  // says so with a flag: > 0 once sigma_w is written, < 0 if it never will be
+  if (sigma_w_ready) {
+    for (;;) {
+      const int v = __atomic_load_n(sigma_w_ready, __ATOMIC_ACQUIRE);
+      if (v > 0) break;
+      if (v < 0) return set_err(WM_ERR_BADARG, "sigma_w was not produced (sigma_w_ready < 0)");
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+  }
   // U diag(alpha Sw) V^T = T diag(e) B  with  e_i = alpha * sw[rank(i)] / (s_i |b_i|^2), rank < K
   // (u_i = T[:, i] / (|b_i| s_i), v_i^T = b_i / |b_i|;  S_[:K] = Sc[:K] + alpha*Sw[:K]).
   std::vector<float> d((size_t)p.B * p.Lp, 0.0f);
@@ -1681,9 +1694,9 @@ int wm_ref_sigma_u8(wm_ctx* ctx, const uint8_t* plane, float* sigma, int H, int 
   return wm_ref_sigma_planes_u8(ctx, plane, sigma, 1, H, W, row_stride, (size_t)H * row_stride);
 }
 
-int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,
-                           float* yw, int n_planes, int H, int W, int row_stride, size_t plane_stride,
-                           size_t sigma_w_plane_stride, float alpha, int K) {
+int wm_ref_embed_planes_u8_when(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, const int* sigma_w_ready,
+                                uint8_t* stego, float* sigma_c, float* yw, int n_planes, int H, int W, int row_stride,
+                                size_t plane_stride, size_t sigma_w_plane_stride, float alpha, int K) {
   WM_TRY(check_ref_args(ctx, host, n_planes, H, W, row_stride, plane_stride));
   if (!sigma_w || !stego || !sigma_c) return set_err(WM_ERR_BADARG, "NULL argument");
   const RefPlan p = make_plan(H, W, n_planes);
@@ -1703,11 +1716,18 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
   if (stego != host) WM_HIP(hipMemcpyAsync(d_out, stego, n_in, hipMemcpyHostToDevice, ctx->stream));
   else WM_HIP(hipMemcpyAsync(d_out, d_in, n_in, hipMemcpyDeviceToDevice, ctx->stream));
   WM_TRY(ref_embed_core(ctx, p, w, d_in, d_out, d_ywout, (size_t)row_stride, plane_stride, w.tmp2,
-                        w.tmp2 + (size_t)n_planes * p.L * p.M, sigma_w, sigma_w_plane_stride, sigma_c, alpha, K));
+                        w.tmp2 + (size_t)n_planes * p.L * p.M, sigma_w, sigma_w_plane_stride, sigma_c, alpha, K, sigma_w_ready));
   WM_HIP(hipMemcpyAsync(stego, d_out, n_in, hipMemcpyDeviceToHost, ctx->stream));
   if (yw) WM_HIP(hipMemcpyAsync(yw, d_ywout, yw_elems * 4, hipMemcpyDeviceToHost, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
   return WM_OK;
+}
+
+int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,
+                           float* yw, int n_planes, int H, int W, int row_stride, size_t plane_stride,
+                           size_t sigma_w_plane_stride, float alpha, int K) {
+  return wm_ref_embed_planes_u8_when(ctx, host, sigma_w, nullptr, stego, sigma_c, yw, n_planes, H, W, row_stride, plane_stride,
+                                     sigma_w_plane_stride, alpha, K);
 }
 
 int wm_ref_embed_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, uint8_t* stego, float* sigma_c,

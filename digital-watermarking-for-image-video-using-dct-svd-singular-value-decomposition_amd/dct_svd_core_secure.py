@@ -42,16 +42,19 @@ TILE = 8
 _tls = threading.local()
 
 
-def _ctx(device: int = 0) -> hostapi.Context:
+def _ctx(device: int = 0, companion: bool = False) -> hostapi.Context:
     """One cached context per (calling thread, device): a context owns its stream and grow-only
     scratch buffers, so two threads inside embed()/extract() at once must not share one (the
-    reference's functions are re-entrant).  Released when the thread ends."""
+    reference's functions are re-entrant).  Released when the thread ends.
+    companion: this thread's second context, handed to the worker that decomposes the watermark while the
+    first one decomposes the host planes (full-frame embed)."""
     cache = getattr(_tls, "contexts", None)
     if cache is None:
         cache = _tls.contexts = {}
-    c = cache.get(device)
+    key = (device, bool(companion))
+    c = cache.get(key)
     if c is None:
-        c = cache[device] = hostapi.Context(device)
+        c = cache[key] = hostapi.Context(device)
     return c
 
 
@@ -162,14 +165,20 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
     if color:
         meta = dict(mode="color", **common)
         Sws = []
-        # single:123-134: the three scrambled watermark planes, their DCTs and SVDs as ONE batch
-        w_s = ctx.permute_planes(np.ascontiguousarray(np.moveaxis(wm, -1, 0)), idx)      # one shared permutation, single:124-126
-        Us, Ss, Vts = ctx.ref_svd_planes(w_s, apply_dct=True)
+        # single:123-134: the three scrambled watermark planes, their DCTs and SVDs as ONE batch - on the companion context
+        # and a worker thread, under the host planes' own decomposition (the two do not depend on each other until
+        # single:139's S + alpha * Sw)
+        ctx_w = _ctx(ctx.device, companion=True)
+
+        def watermark_side():
+            w_s = ctx_w.permute_planes(np.ascontiguousarray(np.moveaxis(wm, -1, 0)), idx)      # one shared permutation, single:124-126
+            Us, Ss, Vts = ctx_w.ref_svd_planes(w_s, apply_dct=True)
+            return Ss, (Us, Ss, Vts)
+        hosts = np.ascontiguousarray(np.moveaxis(cover, -1, 0))            # b, g, r planes, one batched call
+        st, Sc, _, (Us, Ss, Vts) = ctx.ref_embed_planes_when(hosts, watermark_side, True, alpha, K)   # single:127-147
         for ch, n in enumerate("bgr"):
             meta["UW" + n] = np.ascontiguousarray(Us[ch]); meta["VW" + n + "t"] = np.ascontiguousarray(Vts[ch]); meta["SW" + n] = np.ascontiguousarray(Ss[ch])
             Sws.append(meta["SW" + n])
-        hosts = np.ascontiguousarray(np.moveaxis(cover, -1, 0))            # b, g, r planes, one batched call
-        st, Sc, _ = ctx.ref_embed_planes(hosts, np.stack(Sws), alpha, K)   # single:127-147
         for ch, n in enumerate("bgr"):
             meta["S" + n] = Sc[ch]
         stego = np.ascontiguousarray(np.moveaxis(st, 0, -1))
@@ -178,10 +187,15 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
         meta["digest"] = np.frombuffer(digest, dtype=np.uint8)
         return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
                     ssim=ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego)))
+    ctx_w = _ctx(ctx.device, companion=True)
+
+    def watermark_side():                                                  # single:170-171, 173 on the companion context
+        wy_s = ctx_w.permute_planes(ctx_w.color("bgr2gray", wm), idx)
+        Uw, Sw, Vwt = ctx_w.ref_svd(wy_s, apply_dct=True)
+        return Sw, (Uw, Sw, Vwt)
     Y = ctx.color("bgr2y", cover)
-    wy_s = ctx.permute_planes(ctx.color("bgr2gray", wm), idx)
-    Uw, Sw, Vwt = ctx.ref_svd(wy_s, apply_dct=True)                        # single:173
-    stegoY, Sc, Yw = ctx.ref_embed(Y, Sw, alpha, K, want_yw=True)          # single:172-177
+    st, Scs, Yws, (Uw, Sw, Vwt) = ctx.ref_embed_planes_when(Y[None], watermark_side, False, alpha, K, want_yw=True)   # single:172-177
+    stegoY, Sc, Yw = st[0], Scs[0], Yws[0]
     stego = ctx.color("replace_y", cover, stegoY)
     digest = hg.hmac_digest(key, [Sc, Uw, Vwt])
     meta = dict(mode="gray", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw, **common,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "wm_ref_last_sweeps": [_vp, C.POINTER(_i)],
     "wm_ref_last_flops": [_vp, C.POINTER(C.c_double), C.POINTER(_i)],
     "wm_ref_embed_planes_u8": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
+    "wm_ref_embed_planes_u8_when": [_vp, _vp, _vp, C.POINTER(_i), _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_ref_sigma_planes_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
     "wm_ref_embed_planes_u8_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _sz, _f, _i],
     "wm_ref_sigma_planes_u8_dev": [_vp, _vp, _vp, _i, _i, _i, _i, _sz],
@@ -451,6 +452,50 @@ class Context:
                    _vp(sc.ctypes.data), _vp(yw.ctypes.data) if want_yw else None, n, H, W, W, H * W,
                    L if sw.ndim == 2 else 0, float(alpha), int(K))
         return stego, sc, yw
+
+    def ref_embed_planes_when(self, hosts: np.ndarray, produce_sigma_w, per_plane: bool, alpha: float, K: int,
+                              want_yw: bool = False):
+        """``ref_embed_planes`` for a sigma_w that is still being computed: ``produce_sigma_w()`` -> (sigma_w [L] or [N, L],
+        anything) runs on a worker thread - the watermark's own decomposition, on ANOTHER Context - while this context
+        decomposes the host planes (single:172-173 are independent statements; one full-frame SVD leaves most of the chip
+        idle).  Returns (stego, sigma_c, yw, the callable's second value); the callable's exception is re-raised here."""
+        import threading
+        if hosts.dtype != np.uint8 or hosts.ndim != 3:
+            raise ValueError("hosts must be uint8 [N, H, W]")
+        hosts = np.ascontiguousarray(hosts)
+        n, H, W = hosts.shape
+        L = min(H, W)
+        sw = np.zeros((n, L) if per_plane else (L,), np.float32)
+        flag = _i(0)
+        box = {}
+
+        def run():
+            try:
+                s, extra = produce_sigma_w()
+                s = np.asarray(s, dtype=np.float32)
+                if s.shape != sw.shape:
+                    raise ValueError(f"sigma_w must have shape {sw.shape}")
+                sw[...] = s
+                box["extra"] = extra
+                flag.value = 1                                   # read with acquire order by the library
+            except BaseException as e:                           # the embed call returns WM_ERR_BADARG; re-raised below
+                box["exc"] = e
+                flag.value = -1
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        stego = np.empty_like(hosts); sc = np.empty((n, L), np.float32)
+        yw = np.empty((n, H, W), np.float32) if want_yw else None
+        try:
+            self._call("wm_ref_embed_planes_u8_when", _vp(hosts.ctypes.data), _vp(sw.ctypes.data), C.byref(flag),
+                       _vp(stego.ctypes.data), _vp(sc.ctypes.data), _vp(yw.ctypes.data) if want_yw else None, n, H, W, W, H * W,
+                       L if per_plane else 0, float(alpha), int(K))
+        except Exception:
+            t.join()
+            if "exc" in box:
+                raise box["exc"]
+            raise
+        t.join()
+        return stego, sc, yw, box["extra"]
 
     def ref_last_sweeps(self) -> int:
         n = _i(0)

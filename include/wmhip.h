@@ -206,6 +206,14 @@ int wm_ref_embed_planes_u8(wm_ctx* ctx, const uint8_t* host, const float* sigma_
                            size_t plane_stride, size_t sigma_w_plane_stride, float alpha, int K);
 int wm_ref_sigma_planes_u8(wm_ctx* ctx, const uint8_t* planes, float* sigma, int n_planes, int H, int W,
                            int row_stride, size_t plane_stride);
+/* The same embed for a caller that is still computing sigma_w: single:172-173 are two independent decompositions (the host
+ * plane's and the watermark's), and one full-frame SVD occupies a fraction of the chip - run on two contexts and two host
+ * threads they overlap.  sigma_w is first read after the host planes' decomposition; until then *sigma_w_ready may be 0.
+ * The caller stores > 0 (release order) once sigma_w is written, or < 0 to abandon the call (returns WM_ERR_BADARG).
+ * sigma_w_ready == NULL: sigma_w is valid on entry (wm_ref_embed_planes_u8). */
+int wm_ref_embed_planes_u8_when(wm_ctx* ctx, const uint8_t* host, const float* sigma_w, const int* sigma_w_ready,
+                                uint8_t* stego, float* sigma_c, float* yw, int n_planes, int H, int W, int row_stride,
+                                size_t plane_stride, size_t sigma_w_plane_stride, float alpha, int K);
 
 /* Replaces  Wm = dct2(wy_s); Uw, Sw, Vwt = np.linalg.svd(Wm, full_matrices=False)
  * (single:173, 131-134) when apply_dct != 0 (plain thin SVD of the plane otherwise).

@@ -410,3 +410,42 @@ def test_batched_watermark_svd_equals_the_single_plane_calls(gpu_ctx):
             rec = (Ub[z] * Sb[z]) @ Vb[z]
             assert np.max(np.abs(rec - C)) / s64[0] < 2e-5
             assert np.max(np.abs(Ub[z].T @ Ub[z] - np.eye(L))) < 2e-4 and np.max(np.abs(Vb[z] @ Vb[z].T - np.eye(L))) < 2e-4
+
+
+def test_fullframe_embed_with_sigma_w_still_being_computed(gpu_ctx):
+    """wm_ref_embed_planes_u8_when: sigma_w arrives from a worker thread (the watermark's own decomposition on a second
+    context) while the host planes are decomposed - the same bytes as the plain call, per-plane and shared sigma_w; a
+    failing producer is re-raised and the call does not hang."""
+    import importlib
+    import time
+    from conftest import PKG_NAME
+    hostapi = importlib.import_module(PKG_NAME + ".hostapi")
+    rng = np.random.default_rng(21)
+    H, W = 96, 160
+    hosts = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    wm = rng.integers(0, 256, (3, H, W)).astype(np.float32)
+    ctx2 = hostapi.Context(0)
+    try:
+        U, S, Vt = ctx2.ref_svd_planes(wm, apply_dct=True)
+        want = gpu_ctx.ref_embed_planes(hosts, S, 0.15, 60, want_yw=True)
+
+        def produce():
+            time.sleep(0.05)                                          # the host planes' decomposition is long over: the call waits
+            U2, S2, Vt2 = ctx2.ref_svd_planes(wm, apply_dct=True)
+            return S2, ("factors", U2, Vt2)
+        st, sc, yw, extra = gpu_ctx.ref_embed_planes_when(hosts, produce, True, 0.15, 60, want_yw=True)
+        assert np.array_equal(st, want[0]) and np.array_equal(sc, want[1]) and np.array_equal(yw, want[2])
+        assert extra[0] == "factors" and np.array_equal(extra[1], U)
+        st1, sc1, _, _ = gpu_ctx.ref_embed_planes_when(hosts[:1], lambda: (S[0], None), False, 0.15, 60)
+        one = gpu_ctx.ref_embed_planes(hosts[:1], S[0], 0.15, 60)
+        assert np.array_equal(st1, one[0]) and np.array_equal(sc1, one[1])
+
+        def failing():
+            raise RuntimeError("no watermark today")
+        with pytest.raises(RuntimeError, match="no watermark today"):
+            gpu_ctx.ref_embed_planes_when(hosts, failing, True, 0.15, 60)
+        with pytest.raises(ValueError, match="sigma_w must have shape"):
+            gpu_ctx.ref_embed_planes_when(hosts, lambda: (S[0], None), True, 0.15, 60)
+        gpu_ctx.check_status()
+    finally:
+        ctx2.close()
