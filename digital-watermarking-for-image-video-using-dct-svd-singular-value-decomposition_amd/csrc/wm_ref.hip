@@ -272,6 +272,7 @@ __device__ __forceinline__ int rr_elem(const int pos, const int step) {
 // Two-level (super-block) scheme, see "hierarchical block Jacobi" further down: a super-pair is at most HSB
 // 32-row blocks (HN rows); its Gram matrix G_s and accumulated rotation Q_s are HN x HN arrays (pitch HN) in
 // global memory, and a stage rotates HU disjoint block pairs ("units") of it.
+typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int HSB = 12;
 constexpr int HN = HSB * RB;
 constexpr int HU = HSB / 2;
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
       c0 *= nrm; s0 *= nrm;
       const bool sw = tau > 0.0f;
       const float C2 = sw ? s0 : c0, S2 = sw ? -c0 : -s0;
+      const f2v cs2 = {C2, S2}, ns2 = {-S2, C2};
 #pragma unroll
       for (int i = 0; i < INNER_NB; ++i) {
         const int la = 2 * wv_s + INNER_KR * i;            // the lanes that hold the row pairs' rotations (wave-uniform)
@@ -537,18 +539,18 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
         const float S1a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), la));
         const float S1b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S2), la + 1));
         const float C1 = hi ? C1b : C1a, S1 = hi ? S1b : S1a;
-        const float gpp = g[i][0], gpq = g[i][1], gqp = g[i][2], gqq = g[i][3];
-        const float a0 = C2 * gpp - S2 * gpq, a1 = S2 * gpp + C2 * gpq;
-        const float b0 = C2 * gqp - S2 * gqq, b1 = S2 * gqp + C2 * gqq;
-        Gd[rp_[i] + k2] = C1 * a0 - S1 * b0; Gd[rp_[i] + cq] = C1 * a1 - S1 * b1;
-        Gd[rq_[i] + k2] = S1 * a0 + C1 * b0; Gd[rq_[i] + cq] = S1 * a1 + C1 * b1;
+        // two-wide (v_pk_mul_f32 / v_pk_fma_f32): X = row p1 and Y = row q1 with the columns rotated, then the rows
+        const f2v X = g[i][0] * cs2 + g[i][1] * ns2;           // (C2 gpp - S2 gpq, S2 gpp + C2 gpq)
+        const f2v Y = g[i][2] * cs2 + g[i][3] * ns2;
+        const f2v P = C1 * X - S1 * Y, Q = S1 * X + C1 * Y;
+        Gd[rp_[i] + k2] = P.x; Gd[rp_[i] + cq] = P.y;
+        Gd[rq_[i] + k2] = Q.x; Gd[rq_[i] + cq] = Q.y;
       }
 #pragma unroll
       for (int j = 0; j < 2 * INNER_NB; ++j) {
-        const float rp = ri[j], rq = rj[j];
-        ri[j] = C2 * rp - S2 * rq;
-        const float nq = S2 * rp + C2 * rq;
-        rj[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(shl, __float_as_int(nq)));   // lane k2 takes lane k2 + 1's block-J column
+        const f2v rr = ri[j] * cs2 + rj[j] * ns2;              // (C2 rp - S2 rq, S2 rp + C2 rq)
+        ri[j] = rr.x;
+        rj[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(shl, __float_as_int(rr.y)));   // lane k2 takes lane k2 + 1's block-J column
       }
       // next step: column q2 and the rows q1 move on by one, from 63 back to 32
       const bool wc = cq == RP - 1;
