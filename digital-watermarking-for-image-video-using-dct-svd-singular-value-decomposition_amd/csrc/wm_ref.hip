@@ -1133,11 +1133,11 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     float* Gs = hw.Gs + (size_t)z0 * nsp * HN * HN;
     float* R = hw.R + (size_t)z0 * nsp * HU * RP * RP;
     float* par = hw.partials + (size_t)z0 * nsp * HG_TILES * hw.KS * HG_T * HG_T;
-    int* skip = hw.skip + (size_t)z0 * nsp * HU;
-    int* anyrot = hw.anyrot + (size_t)z0 * nsp;
+    int* skip = hier_flag_base(hw.skip, (size_t)nsp * HU, z0, g);
+    int* anyrot = hier_flag_base(hw.anyrot, (size_t)nsp, z0, g);
     // per-stage rotations (packed) and skip flags of this group's planes: [stage][plane][super-pair * HU + unit]
     float* Rpk = hw.Rpk + (size_t)z0 * HT_MAX * nsp * HU * RP * RP;
-    int* skipT = hw.skipT + (size_t)z0 * HT_MAX * nsp * HU;
+    int* skipT = hier_flag_base(hw.skipT, (size_t)HT_MAX * nsp * HU, z0, g);
     const size_t rpk_stage = (size_t)nz * nsp * HU * RP * RP, skip_stage = (size_t)nz * nsp * HU;
     const int n32 = ht->nmax * RB, npmax = (n32 + HG_T - 1) / HG_T;
     const int nchunk = (p.M + HG_KC - 1) / HG_KC;
