@@ -299,6 +299,12 @@ __global__ __launch_bounds__(INNER_NT) void k_rf_inner(const float* __restrict__
   __shared__ float R[RP][RP + 1];
   __shared__ float red[INNER_NW];
   const int t = threadIdx.x, p = blockIdx.x;
+#if defined(WM_POISON_LDS)     // diagnostic: every word of the kernel's LDS starts as a NaN - a read of a word the kernel never wrote shows in the results
+  for (int i = threadIdx.x; i < 2 * RP * (RP + 1); i += INNER_NT) (&GG[0][0][0])[i] = __int_as_float(0x7fc00000);
+  for (int i = threadIdx.x; i < RP * (RP + 1); i += INNER_NT) (&R[0][0])[i] = __int_as_float(0x7fc00000);
+  if (threadIdx.x < INNER_NW) red[threadIdx.x] = __int_as_float(0x7fc00000);
+  __syncthreads();
+#endif
 #if defined(WM_INNER_DIAG)     // diagnostic build only (tools/): where one inner solve spends its cycles
   unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, st3 = 0;
 #endif
