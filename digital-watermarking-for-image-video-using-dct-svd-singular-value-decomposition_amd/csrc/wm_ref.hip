@@ -961,7 +961,7 @@ int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, 
   const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * GRAM_PART * 4),
                o_R = take(B * p.npairs * RP * RP * 4),
                o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_skip = take(B * p.npairs * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
-               o_d = take(B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
+               o_d = take(2 * B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
                o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
   if (which == 0) WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
   else WM_TRY(grow(ctx, &ctx->ref_ws2, &ctx->ref_ws2_bytes, off, "full-frame completion workspace"));
@@ -981,15 +981,15 @@ int fill_dct(wm_ctx* ctx, int n, int slot) {
     WM_HIP(hipFree(ctx->dct_mat[slot]));
     ctx->dct_mat[slot] = nullptr; ctx->dct_n[slot] = 0;
   }
-  if (hipMalloc((void**)&ctx->dct_mat[slot], (size_t)n * n * 4) != hipSuccess) {
+  if (hipMalloc((void**)&ctx->dct_mat[slot], (size_t)2 * n * n * 4) != hipSuccess) {       // D, then D^T (row-major A operand of the split-f16 inverse DCT)
     (void)hipGetLastError();
     return set_err(WM_ERR_NOMEM, "hipMalloc failed for %s", "DCT basis");
   }
-  std::vector<float> D((size_t)n * n);
+  std::vector<float> D((size_t)2 * n * n);
   const double pi = 3.14159265358979323846;
   for (int k = 0; k < n; ++k) {
     const double s = (k == 0) ? sqrt(1.0 / n) : sqrt(2.0 / n);
-    for (int m = 0; m < n; ++m) D[(size_t)k * n + m] = (float)(s * cos(pi * (2.0 * m + 1.0) * k / (2.0 * n)));
+    for (int m = 0; m < n; ++m) D[(size_t)n * n + (size_t)m * n + k] = D[(size_t)k * n + m] = (float)(s * cos(pi * (2.0 * m + 1.0) * k / (2.0 * n)));
   }
   WM_HIP(hipMemcpyAsync(ctx->dct_mat[slot], D.data(), D.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -1248,11 +1248,23 @@ int fetch_norms(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std:
 // of the embed (u_i = T[:, i] / (|b_i| s_i)).  b2 = |b_i|^2, and q2 is returned as
 // b2^2 / |T[:, i]|^2 so that sqrt(b2 / q2) is s_i like in the [A | I] formulation.
 //   A0: dense [B][L][M] copy of the input rows;  T: dense [B][L][Lp] (left on the device).
+// The finalisation's large products from split-f16 operands (k_hgemm, wm_ref_hier.inc) unless WM_RF_FINAL_F16=0 or the shapes
+// do not allow 16-byte loads; the f32 k_sgemm otherwise.
+static bool final_f16() {
+  static const bool on = !(getenv("WM_RF_FINAL_F16") && atoi(getenv("WM_RF_FINAL_F16")) == 0);
+  return on;
+}
+
 int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0, float* T, std::vector<double>& b2,
                   std::vector<double>& q2, std::vector<unsigned char>* reliable = nullptr,
                   std::vector<double>* t2_raw = nullptr) {
   // all planes' products in one launch (grid.z = plane)
   hipLaunchKernelGGL(k_rf_rownorms, dim3(p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, 0, w.b2, w.q2);
+  if (final_f16() && hgemm_ok(A0, p.M, w.aug, p.ld)) {
+    // A0 holds uint8 samples (every caller decomposes uint8 planes): exact in f16; B's rows are bounded by 255 sqrt(L)
+    hipLaunchKernelGGL((k_hgemm<true, true, false>), dim3((p.Lp + 127) / 128, (p.L + 127) / 128, p.B), dim3(256), 0, ctx->stream, p.L, p.Lp, p.M,
+                       A0, p.M, (size_t)p.L * p.M, w.aug, p.ld, p.aug_ps, 0, T, p.Lp, (size_t)p.L * p.Lp, (const float*)nullptr, (size_t)0, 1.0f);
+  } else
   WM_TRY(sgemm_b(ctx, false, true, p.L, p.Lp, p.M, 1.0f, A0, p.M, (size_t)p.L * p.M, w.aug, p.ld, p.aug_ps, 0.0f, T, p.Lp,
                  (size_t)p.L * p.Lp, p.B));
   hipLaunchKernelGGL(k_rf_colnorms, dim3((p.Lp + 63) / 64, p.B), dim3(256), 0, ctx->stream, T, (size_t)p.L * p.Lp, p.L, p.Lp, w.q2);
@@ -1497,7 +1509,15 @@ int ref_embed_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t*
   }
   // U diag(alpha Sw) V^T = T diag(e) B  with  e_i = alpha * sw[rank(i)] / (s_i |b_i|^2), rank < K
   // (u_i = T[:, i] / (|b_i| s_i), v_i^T = b_i / |b_i|;  S_[:K] = Sc[:K] + alpha*Sw[:K]).
-  std::vector<float> d((size_t)p.B * p.Lp, 0.0f);
+  // Split-f16 form of the product (k_hgemm): the factor e_i = ca_i cb_i goes half to each operand - B's rows to unit norm
+  // (cb_i = 1 / |b_i|), T's columns to alpha sw (ca_i = alpha sw / (s_i |b_i|)) - so that both are inside f16's range whatever
+  // the plane's scale; alpha * max(sw) must be (f32 product otherwise).
+  bool f16_prod = final_f16() && hgemm_ok(d_t, p.Lp, w.aug, p.ld) && p.M % 4 == 0;
+  for (int z = 0; z < p.B && f16_prod; ++z) {
+    const float* sw = sigma_w + (size_t)z * sigma_w_plane_stride;
+    for (int k = 0; k < std::min(K, p.L); ++k) if (!(fabs((double)alpha * sw[k]) < 3.0e4)) { f16_prod = false; break; }
+  }
+  std::vector<float> d((size_t)p.B * p.Lp * (f16_prod ? 2 : 1), 0.0f);       // row scales of B [, then column scales of T]
   std::vector<int> order; std::vector<float> sig;
   struct Todo { int z; std::vector<unsigned char> valid; std::vector<float> wk; std::vector<double> t2; };
   std::vector<Todo> todo;
@@ -1517,8 +1537,13 @@ int ref_embed_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t*
     for (int k = 0; k < std::min(K, p.L); ++k) {
       const int i = order[k];
       const double si = (double)sig[k];
-      if (td.valid[i]) d[(size_t)z * p.Lp + i] = (float)((double)alpha * (double)sw[k] / (si * pb[i]));
-      else td.wk.push_back(alpha * sw[k]);           // rank k has no singular direction in this plane: completed below
+      if (td.valid[i]) {
+        if (f16_prod) {
+          const double nb = sqrt(pb[i]);
+          d[(size_t)z * p.Lp + i] = (float)(1.0 / nb);
+          d[(size_t)(p.B + z) * p.Lp + i] = (float)((double)alpha * (double)sw[k] / (si * nb));
+        } else d[(size_t)z * p.Lp + i] = (float)((double)alpha * (double)sw[k] / (si * pb[i]));
+      } else td.wk.push_back(alpha * sw[k]);           // rank k has no singular direction in this plane: completed below
     }
     if (!td.wk.empty()) todo.push_back(std::move(td));
   }
@@ -1532,6 +1557,10 @@ int ref_embed_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t*
   }
   hipLaunchKernelGGL(k_rf_scale_rows, dim3(8, p.Lp, p.B), dim3(256), 0, ctx->stream, w.aug, p.aug_ps, p.ld, p.M, w.dvec);
   // Yw += T (diag(e) B):   [L x Lp] times [Lp x M], all planes in one launch
+  if (f16_prod)
+    hipLaunchKernelGGL((k_hgemm<false, false, true>), dim3((p.M + 127) / 128, (p.L + 127) / 128, p.B), dim3(256), 0, ctx->stream, p.L, p.M, p.Lp,
+                       d_t, p.Lp, (size_t)p.L * p.Lp, w.aug, p.ld, p.aug_ps, 1, d_yw, p.M, yw_ps, w.dvec + (size_t)p.B * p.Lp, (size_t)p.Lp, 1.0f);
+  else
   WM_TRY(sgemm_b(ctx, false, false, p.L, p.M, p.Lp, 1.0f, d_t, p.Lp, (size_t)p.L * p.Lp, w.aug, p.ld, p.aug_ps, 1.0f,
                  d_yw, p.M, yw_ps, p.B));
   hipLaunchKernelGGL(k_rf_quant, dim3(8, p.H, p.B), dim3(256), 0, ctx->stream, d_yw, yw_ps, p.M, p.transpose ? 1 : 0,
@@ -1550,9 +1579,32 @@ int ref_embed_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const uint8_t*
 int ref_reconstruct_core(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const std::vector<float>& sh, const int Lx,
                          const float* d_uw, const float* d_vwt, float* d_us, float* d_mid, float* d_out) {
   const int L = p.L, H = p.H, W = p.W;
-  WM_HIP(hipMemcpyAsync(w.dvec, sh.data(), sh.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   float *dH, *dW;
   WM_TRY(get_dct_pair(ctx, H, W, &dH, &dW));
+  if (final_f16() && L % 4 == 0 && W % 4 == 0 && H % 4 == 0 && hgemm_ok(d_uw, L, d_vwt, W) && hgemm_ok(d_mid, W, d_out, W)) {
+    // Split-f16 products (k_hgemm): Uw, Vwt and the DCT bases are orthonormal; the estimates are scaled by a power of two so
+    // that |X| <= max |sw_hat| * scale stays below 3e4, and the last product multiplies it out again (exact both ways).
+    float mx = 0.0f;
+    for (float v : sh) mx = fmaxf(mx, fabsf(v));
+    int e = 0;
+    if (mx > 0.0f && std::isfinite(mx)) { (void)frexpf(mx / 3.0e4f, &e); if (e < 0) e = 0; }
+    const float scale = ldexpf(1.0f, -e);
+    std::vector<float> shs(sh);
+    for (float& v : shs) v *= scale;
+    WM_HIP(hipMemcpyAsync(w.dvec, shs.data(), shs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemsetAsync(d_out, 0, (size_t)p.B * H * W * 4, ctx->stream));                                   // single:215
+    const float* dHt = dH + (size_t)H * H;
+    hipLaunchKernelGGL((k_hgemm<false, false, true>), dim3((Lx + 127) / 128, (Lx + 127) / 128, p.B), dim3(256), 0, ctx->stream, Lx, Lx, Lx,
+                       d_uw, L, (size_t)0, d_vwt, W, (size_t)0, 0, d_out, W, (size_t)H * W, w.dvec, (size_t)p.Lp, 1.0f);          // single:214, 216-217
+    hipLaunchKernelGGL((k_hgemm<false, false, false>), dim3((W + 127) / 128, (H + 127) / 128, p.B), dim3(256), 0, ctx->stream, H, W, H,
+                       dHt, H, (size_t)0, d_out, W, (size_t)H * W, 0, d_mid, W, (size_t)H * W, (const float*)nullptr, (size_t)0, 1.0f);   // idct2: D_H^T X
+    hipLaunchKernelGGL((k_hgemm<false, false, false>), dim3((W + 127) / 128, (H + 127) / 128, p.B), dim3(256), 0, ctx->stream, H, W, W,
+                       d_mid, W, (size_t)H * W, dW, W, (size_t)0, 0, d_out, W, (size_t)H * W, (const float*)nullptr, (size_t)0, 1.0f / scale);   //        ... D_W   single:218
+    WM_HIP(hipGetLastError());
+    WM_HIP(hipStreamSynchronize(ctx->stream));       // (shs is a local)
+    return WM_OK;
+  }
+  WM_HIP(hipMemcpyAsync(w.dvec, sh.data(), sh.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   // Uw[:Lx,:Lx] * sh (column scaling) per plane: the first Lx rows of Uw (leading dimension L)
   hipLaunchKernelGGL(k_rf_scale_cols_b, dim3(8, Lx, p.B), dim3(256), 0, ctx->stream, d_uw, (size_t)0, d_us, (size_t)L * L, L,
                      w.dvec, (size_t)p.Lp);
