@@ -1250,9 +1250,9 @@ int fetch_norms(wm_ctx* ctx, const RefPlan& p, const RefWs& w, bool with_q, std:
 //   A0: dense [B][L][M] copy of the input rows;  T: dense [B][L][Lp] (left on the device).
 // The finalisation's large products from split-f16 operands (k_hgemm, wm_ref_hier.inc) unless WM_RF_FINAL_F16=0 or the shapes
 // do not allow 16-byte loads; the f32 k_sgemm otherwise.
-static bool final_f16() {
-  static const bool on = !(getenv("WM_RF_FINAL_F16") && atoi(getenv("WM_RF_FINAL_F16")) == 0);
-  return on;
+static bool final_f16() {            // (read on every call, like WM_RF_HIER: tests switch it)
+  const char* e = getenv("WM_RF_FINAL_F16");
+  return !(e && atoi(e) == 0);
 }
 
 int fetch_norms_t(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const float* A0, float* T, std::vector<double>& b2,

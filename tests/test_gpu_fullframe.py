@@ -449,3 +449,31 @@ def test_fullframe_embed_with_sigma_w_still_being_computed(gpu_ctx):
         gpu_ctx.check_status()
     finally:
         ctx2.close()
+
+
+def test_fullframe_split_f16_finalisation_against_the_f32_products(gpu_ctx, monkeypatch):
+    """The finalisation's large products (T = A0 B^T, the embed's U diag V^T, the extract's Uw diag Vwt and inverse DCT) run from
+    split-f16 operands on the f16 matrix pipe (k_hgemm); WM_RF_FINAL_F16=0 keeps the f32 k_sgemm.  Same singular values to
+    1e-6 sigma_1, stego within 1 LSB on a handful of pixels, extracted planes within 1e-4 of their range - on a shape with
+    ragged tiles (200 x 328), a portrait one, and a plane whose alpha * sw exceeds f16's range (falls back by itself)."""
+    rng = np.random.default_rng(17)
+    for (H, W, alpha, swmax) in ((200, 328, 0.15, 3e4), (328, 200, 0.2, 1e4), (256, 384, 1.0, 2e5)):
+        L = min(H, W)
+        hosts = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+        sw = np.sort(rng.uniform(1.0, swmax, L).astype(np.float32))[::-1].copy()
+        K = int(0.6 * L)
+        wm = rng.integers(0, 256, (H, W)).astype(np.float32)
+        Uw, Sw, Vwt = gpu_ctx.ref_svd(wm, apply_dct=True)
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("WM_RF_FINAL_F16", flag)
+            st, sc, yw = gpu_ctx.ref_embed_planes(hosts, sw, alpha, K, want_yw=True)
+            ex = gpu_ctx.ref_extract_planes(st, sc, Uw, Vwt, alpha, K)
+            out[flag] = (st, sc, yw, ex)
+        a, b = out["1"], out["0"]
+        assert np.max(np.abs(a[1] - b[1])) < 1e-6 * b[1].max()
+        d = np.abs(a[0].astype(int) - b[0].astype(int))
+        assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+        assert np.max(np.abs(a[2] - b[2])) < 2e-2                         # Yw before the quantiser, grey levels
+        assert np.max(np.abs(a[3] - b[3])) < 1e-4 * np.max(np.abs(b[3]))
+    gpu_ctx.check_status()
