@@ -1045,7 +1045,7 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
   static const int full_sweeps = getenv("WM_RF_FULL_SWEEPS") ? atoi(getenv("WM_RF_FULL_SWEEPS")) : FULL_INNER_SWEEPS;
   // number of plane groups (HIP queues): WM_RF_QUEUES=n (1..4), WM_RF_ONE_QUEUE=1 is the old spelling of n = 1
   // default: two groups, three from 12 planes on (16 planes: 131 -> 137 frames/s on two boxes, 24: 138 -> 139; 8 planes: 107 / 106)
-  static const int env_queues = [] {
+  const int env_queues = [] {          // (read on every call)
     if (getenv("WM_RF_ONE_QUEUE") && atoi(getenv("WM_RF_ONE_QUEUE"))) return 1;
     const int n = getenv("WM_RF_QUEUES") ? atoi(getenv("WM_RF_QUEUES")) : 0;
     return n < 1 ? 0 : (n > 1 + wm_ctx::MAX_AUX ? 1 + wm_ctx::MAX_AUX : n);

@@ -145,3 +145,19 @@ def test_two_level_is_reproducible_at_1080p(gpu_ctx, monkeypatch):
     for s in runs:
         assert np.max(np.abs(s - ref) / ref[:, :1]) < 2e-6
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
+def test_two_level_on_one_two_and_three_queues(gpu_ctx, monkeypatch):
+    """The plane groups of a batch run on 1 - 3 HIP queues (WM_RF_QUEUES, read per call): the same singular values to 1e-6 sigma_1
+    whatever the grouping (a group's column splits differ with its size, so not bit for bit), every grouping reproducible."""
+    planes = _planes(6, 320, 480, seed=23)
+    ref = np.stack([np.linalg.svd(p.astype(np.float64), compute_uv=False) for p in planes])
+    got = {}
+    for q in ("1", "2", "3"):
+        monkeypatch.setenv("WM_RF_QUEUES", q)
+        a = gpu_ctx.ref_sigma_planes(planes)
+        b = gpu_ctx.ref_sigma_planes(planes)
+        assert np.array_equal(a, b), q
+        assert np.max(np.abs(a - ref) / ref[:, :1]) < 2e-6, q
+        got[q] = a
+    assert np.max(np.abs(got["1"] - got["3"]) / ref[:, :1]) < 1e-6 and np.max(np.abs(got["2"] - got["3"]) / ref[:, :1]) < 1e-6
