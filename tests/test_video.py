@@ -38,6 +38,13 @@ def test_y4m_roundtrip(tmp_path):
         v.Y4M(str(tmp_path / "bad.y4m"))
     sh = importlib.import_module(PKG_NAME + ".sharding")
     assert [sh.frame_range(r, 4, 9) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 9)]
+    # 4:4:4 (the colour functions' container): full-resolution chroma planes, Cb then Cr
+    c444 = np.random.default_rng(2).integers(0, 256, (2, 2 * 64 * 96), dtype=np.uint8)
+    p444 = str(tmp_path / "c444.y4m")
+    v.write_y4m(p444, ys[:2], c444, chroma_tag="444")
+    v4 = v.Y4M(p444); fr = [(y.copy(), c.copy()) for _, y, c in v4]; v4.close()
+    assert v4.chroma == "444" and (v4.cw, v4.ch) == (96, 64) and len(fr) == 2
+    assert np.array_equal(fr[1][0], ys[1]) and np.array_equal(fr[1][1], c444[1])
 
 
 @pytest.mark.gpu
