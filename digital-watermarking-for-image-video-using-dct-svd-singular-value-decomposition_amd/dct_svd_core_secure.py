@@ -182,11 +182,12 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
         for ch, n in enumerate("bgr"):
             meta["S" + n] = Sc[ch]
         stego = np.ascontiguousarray(np.moveaxis(st, 0, -1))
-        digest = hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"], meta["UWb"], meta["UWg"], meta["UWr"],
-                                      meta["VWbt"], meta["VWgt"], meta["VWrt"]])
-        meta["digest"] = np.frombuffer(digest, dtype=np.uint8)
-        return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
-                    ssim=ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego)))
+        dg = _Later(lambda: hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"], meta["UWb"], meta["UWg"], meta["UWr"],
+                                                 meta["VWbt"], meta["VWgt"], meta["VWrt"]]))   # single:152-156, under the metrics (39 MB at 1080p)
+        ps = ctx.psnr(cover, stego)
+        ss = ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego))
+        meta["digest"] = np.frombuffer(dg.result(), dtype=np.uint8)
+        return dict(stego=stego, meta=meta, psnr=ps, ssim=ss)
     ctx_w = _ctx(ctx.device, companion=True)
 
     def watermark_side():                                                  # single:170-171, 173 on the companion context
@@ -196,12 +197,13 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
     Y = ctx.color("bgr2y", cover)
     st, Scs, Yws, (Uw, Sw, Vwt) = ctx.ref_embed_planes_when(Y[None], watermark_side, False, alpha, K, want_yw=True)   # single:172-177
     stegoY, Sc, Yw = st[0], Scs[0], Yws[0]
+    dg = _Later(lambda: hg.hmac_digest(key, [Sc, Uw, Vwt]))               # single:182, under the colour conversion and the metrics
     stego = ctx.color("replace_y", cover, stegoY)
-    digest = hg.hmac_digest(key, [Sc, Uw, Vwt])
+    ps = ctx.psnr(cover, stego)
+    ss = ctx.ssim(ctx.color("bgr2gray", cover), Yw)
     meta = dict(mode="gray", Sc=Sc, Uw=Uw, Vwt=Vwt, Sw=Sw, **common,
-                digest=np.frombuffer(digest, dtype=np.uint8))
-    return dict(stego=stego, meta=meta, psnr=ctx.psnr(cover, stego),
-                ssim=ctx.ssim(ctx.color("bgr2gray", cover), Yw))
+                digest=np.frombuffer(dg.result(), dtype=np.uint8))
+    return dict(stego=stego, meta=meta, psnr=ps, ssim=ss)
 
 
 def _meta_tile(meta) -> Optional[int]:
