@@ -181,9 +181,9 @@ def _embed_arrays_fullframe(ctx, cover, wm, key, idx, nonce, alpha, color, kfrac
             Sws.append(meta["SW" + n])
         for ch, n in enumerate("bgr"):
             meta["S" + n] = Sc[ch]
-        stego = np.ascontiguousarray(np.moveaxis(st, 0, -1))
         dg = _Later(lambda: hg.hmac_digest(key, [meta["Sb"], meta["Sg"], meta["Sr"], meta["UWb"], meta["UWg"], meta["UWr"],
-                                                 meta["VWbt"], meta["VWgt"], meta["VWrt"]]))   # single:152-156, under the metrics (39 MB at 1080p)
+                                                 meta["VWbt"], meta["VWgt"], meta["VWrt"]]))   # single:152-156 (39 MB at 1080p: 16 ms), under the interleave and the metrics
+        stego = np.ascontiguousarray(np.moveaxis(st, 0, -1))
         ps = ctx.psnr(cover, stego)
         ss = ctx.ssim(ctx.color("bgr2gray", cover), ctx.color("bgr2gray", stego))
         meta["digest"] = np.frombuffer(dg.result(), dtype=np.uint8)
