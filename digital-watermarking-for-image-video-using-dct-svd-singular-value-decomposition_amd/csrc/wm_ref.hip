@@ -960,7 +960,7 @@ int plan_workspace(wm_ctx* ctx, const RefPlan& p, RefWs& w, size_t extra_f32_a, 
   const size_t B = (size_t)p.B;
   const size_t o_aug = take(B * p.aug_ps * 4), o_par = take(B * p.npairs * p.nch * GRAM_PART * 4),
                o_R = take(B * p.npairs * RP * RP * 4),
-               o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_skip = take(B * p.npairs * 4 + 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
+               o_mc = take(B * 4 + 256), o_fl = take(B * 4 + 256), o_skip = take(B * p.npairs * 4 + (size_t)(2 + wm_ctx::MAX_AUX) * 256), o_b2 = take(B * p.Lp * 8), o_q2 = take(B * p.Lp * 8),
                o_d = take(2 * B * p.Lp * 4), o_ord = take((size_t)p.Lp * 4), o_sc = take((size_t)p.Lp * 4),
                o_t1 = take(extra_f32_a * 4), o_t2 = take(extra_f32_b * 4);
   if (which == 0) WM_TRY(grow(ctx, &ctx->ref_ws, &ctx->ref_ws_bytes, off, "full-frame workspace"));
@@ -1094,11 +1094,11 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
       hipLaunchKernelGGL(k_rf_gram, dim3(p.npairs, p.nch, nz), dim3(256), 0, st, aug, p.aug_ps, p.ld, p.M, pr, par);
     if (part & 2) {
       hipLaunchKernelGGL(k_rf_inner, dim3(p.npairs, 1, nz), dim3(INNER_NT), 0, st, par, p.nch, R, w.maxcos + z0,
-                         w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1, w.skip + (size_t)z0 * p.npairs,
+                         w.floor2 + z0, (s == 0 || sweep < full_sweeps) ? 0 : 1, hier_flag_base(w.skip, (size_t)p.npairs, z0, g),
                          skip_thr, (const int*)nullptr, (float*)nullptr, (int*)nullptr, 0, (float*)nullptr, (int*)nullptr, 0);
       const int n_blk = (ncols + 31) / 32, per_wg = 4 * p.apply_tiles;     // 32-column blocks, 4 waves per workgroup
       hipLaunchKernelGGL(k_rf_apply, dim3(p.npairs, (n_blk + per_wg - 1) / per_wg, nz), dim3(256), 0, st,
-                         aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R, w.skip + (size_t)z0 * p.npairs);
+                         aug, p.aug_ps, p.ld, ncols, p.apply_tiles, pr, R, hier_flag_base(w.skip, (size_t)p.npairs, z0, g));
     }
   };
   // Two-level scheme (wm_ref_hier.inc): the same rotations with the rows streamed 3 times per SUPER-step.
