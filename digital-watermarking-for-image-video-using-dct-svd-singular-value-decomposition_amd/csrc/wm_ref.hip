@@ -1147,9 +1147,15 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     const size_t rpk_stage = (size_t)nz * nsp * HU * RP * RP, skip_stage = (size_t)nz * nsp * HU;
     const int n32 = ht->nmax * RB, npmax = (n32 + HG_T - 1) / HG_T;
     const int nchunk = (p.M + HG_KC - 1) / HG_KC;
-    const int KS = hier_ks(nsp, nz, npmax, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
+    // (one workgroup per (super-pair, plane, split) instead of three: only where that still fills the chip - from 11 planes per launch on;
+    //  16 planes on three queues: 209 against 213 frames/s with it, 64 planes: 308 against 297)
+    const bool h3 = getenv("WM_RF_HGRAM3") ? atoi(getenv("WM_RF_HGRAM3")) != 0 : nsp * hw.KS * nz >= 256;
+    const int KS = hier_ks(nsp, nz, (gram_f16 && npmax == 3 && h3) ? 1 : npmax, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
     const int ngrp = nsp * KS * nz;               // (super-pair, split, plane) groups of npmax workgroups, dealt over the XCDs
-    if (gram_f16)
+    if (gram_f16 && npmax == 3 && h3)               // three panels: the rows fetched once per chunk (k_hgram_h3)
+      hipLaunchKernelGGL(k_hgram_h3, dim3(((ngrp + 7) / 8) * 8), dim3(H3_NT), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
+                         par, KS, cps, nz);
+    else if (gram_f16)
       hipLaunchKernelGGL(k_hgram_h, dim3(((ngrp + 7) / 8) * 8 * npmax), dim3(512), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
                          par, KS, cps, npmax, nz);
     else

@@ -161,3 +161,22 @@ def test_two_level_on_one_two_and_three_queues(gpu_ctx, monkeypatch):
         assert np.max(np.abs(a - ref) / ref[:, :1]) < 2e-6, q
         got[q] = a
     assert np.max(np.abs(got["1"] - got["3"]) / ref[:, :1]) < 1e-6 and np.max(np.abs(got["2"] - got["3"]) / ref[:, :1]) < 1e-6
+
+
+@pytest.mark.parametrize("H,W", [(832, 900), (1080, 1920), (400, 1000)])
+def test_three_panel_gram_kernel(gpu_ctx, monkeypatch, H, W):
+    """k_hgram_h3 (one workgroup per super-pair, plane and column split: all <= 384 rows of a chunk fetched once, the 78 blocks of the
+    upper triangle shared out over 12 waves) is the default from 11 planes per launch on; forced here on two planes: the same
+    singular values as the two-panel kernel to 5e-7 sigma_1, within the suite's bar of float64 LAPACK, bit-reproducible, also for
+    super-pairs of 10 blocks (832 rows: 26 blocks) and row lengths that are no multiple of the chunk (W = 900, 1000)."""
+    planes = _planes(2, H, W, seed=31)
+    ref = np.stack([np.linalg.svd(p.astype(np.float64), compute_uv=False) for p in planes])
+    monkeypatch.setenv("WM_RF_HGRAM3", "0")
+    a = gpu_ctx.ref_sigma_planes(planes)
+    monkeypatch.setenv("WM_RF_HGRAM3", "1")
+    b = gpu_ctx.ref_sigma_planes(planes)
+    c = gpu_ctx.ref_sigma_planes(planes)
+    assert gpu_ctx.ref_last_flops()[1] is True
+    assert np.array_equal(b, c)
+    assert np.max(np.abs(b - ref) / ref[:, :1]) < 2e-6
+    assert np.max(np.abs(a - b) / ref[:, :1]) < 5e-7
