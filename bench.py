@@ -457,7 +457,7 @@ def fullframe_section(a, torch, dist, api, dev, rank, world, ctx, steps, warmup,
                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                         "achieved_algorithmic": achieved_alg, "frac_algorithmic": achieved_alg / MFMA_F32_PEAK_TFLOPS,
                         "algorithmic_flops_per_launch": alg_flops,
-                        "kernel": ("two-level block Jacobi (k_hgram_h + k_happly_h + k_hupdate products)" if two_level else
+                        "kernel": ("two-level block Jacobi (k_hgram_h[3] + k_happly_h + k_hupdate products)" if two_level else
                                    "block-Jacobi step (k_rf_gram + k_rf_apply GEMM tiles)"),
                         "matrix_pipe": ("f16, split operands: 3 x v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 tile product (f32-class accuracy)"
                                         if split_f16 else "f32: v_mfma_f32_32x32x2_f32"),
@@ -622,7 +622,7 @@ def live_pmc_fullframe(a, timeout_s=240):
     env = dict(os.environ, TMPDIR="/tmp", WM_BENCH_NO_V16="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    jac = ("k_rf_gram", "k_rf_inner", "k_rf_apply", "k_hgram_h", "k_happly_h", "k_hgram", "k_hreduce", "k_hupdate", "k_happly")
+    jac = ("k_rf_gram", "k_rf_inner", "k_rf_apply", "k_hgram_h3", "k_hgram_h", "k_happly_h", "k_hgram", "k_hreduce", "k_hupdate", "k_happly")
     tot, per_kernel, calls = {}, {}, 0
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -1150,7 +1150,8 @@ int jacobi_rows(wm_ctx* ctx, const RefPlan& p, const RefWs& w, const JacobiUse u
     // (one workgroup per (super-pair, plane, split) instead of three: only where that still fills the chip - from 11 planes per launch on;
     //  16 planes on three queues: 209 against 213 frames/s with it, 64 planes: 308 against 297)
     const bool h3 = getenv("WM_RF_HGRAM3") ? atoi(getenv("WM_RF_HGRAM3")) != 0 : nsp * hw.KS * nz >= 256;
-    const int KS = hier_ks(nsp, nz, (gram_f16 && npmax == 3 && h3) ? 1 : npmax, nchunk, hw.KS), cps = (nchunk + KS - 1) / KS;
+    const bool use_h3 = gram_f16 && npmax == 3 && h3;     // (its column splits weigh more: every split writes the whole upper triangle - 2.0 against 0.25: +2 % at 64 and 128 planes)
+    const int KS = hier_ks(nsp, nz, use_h3 ? 1 : npmax, nchunk, hw.KS, use_h3 ? 2.0 : 0.25), cps = (nchunk + KS - 1) / KS;
     const int ngrp = nsp * KS * nz;               // (super-pair, split, plane) groups of npmax workgroups, dealt over the XCDs
     if (gram_f16 && npmax == 3 && h3)               // three panels: the rows fetched once per chunk (k_hgram_h3)
       hipLaunchKernelGGL(k_hgram_h3, dim3(((ngrp + 7) / 8) * 8), dim3(H3_NT), 0, st, aug, p.aug_ps, p.ld, p.M, sup, nsp,
